@@ -1,0 +1,185 @@
+/* libilvlm_hip.so -- C ABI of the MI355X (gfx950) kernels behind the CLIP / CLIP+FDT contrastive
+ * training step of hellomuffin/iterated-learning-for-vlm.
+ *
+ * The reference has no FFI layer: its hot path is a sequence of ATen ops reached through torch.nn
+ * (SURVEY.md section 2.2).  Each entry point below replaces one such op sequence; the reference
+ * call site it stands for is cited as file:line relative to the reference root.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch's
+ *    caching allocator); the library never allocates, frees or retains device memory.
+ *  - every function returns 0 on success, ILVLM_ERR_ARG (<0) for a rejected argument or a positive
+ *    hipError_t; the message is in the thread-local ilvlm_last_error().  No exceptions, no exit().
+ *  - launches are asynchronous on `stream` (a hipStream_t passed as void*); re-entrant, no global
+ *    mutable state (forward runs on the main thread, backward on autograd's worker thread).
+ *  - dtype arguments: ILVLM_F32 or ILVLM_BF16.  "T" below means "the dtype argument of that call".
+ *  - all matrices are row-major with the row stride given where it can differ from the width.
+ *  - gradient outputs documented as "+=" are ACCUMULATED (fp32 atomics) into zero-initialised or
+ *    previously accumulated buffers, which is autograd's .grad semantics.
+ */
+#ifndef ILVLM_HIP_H
+#define ILVLM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILVLM_VERSION 100 /* round 1 */
+
+enum { ILVLM_OK = 0, ILVLM_ERR_ARG = -1 };
+enum { ILVLM_F32 = 0, ILVLM_BF16 = 1 };
+enum {
+    ILVLM_ACT_NONE = 0,
+    ILVLM_ACT_QUICKGELU = 1,     /* out = x*sigmoid(1.702x); pre-activation stored to aux  (base_transformer.py:24-26) */
+    ILVLM_ACT_GELU_ERF = 2,      /* out = exact-erf GELU;     pre-activation stored to aux  (clip_fdt.py:89)          */
+    ILVLM_ACT_QUICKGELU_BWD = 3, /* out = acc * quickgelu'(aux)                                                        */
+    ILVLM_ACT_GELU_ERF_BWD = 4   /* out = acc * gelu_erf'(aux)                                                         */
+};
+enum { ILVLM_POOL_MAX = 0, ILVLM_POOL_MEAN = 1, ILVLM_POOL_SUM = 2 };
+
+int ilvlm_version(void);
+const char* ilvlm_last_error(void);
+
+/* ---- GEMM with fused epilogue --------------------------------------------------------------
+ * C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
+ *   trans_a = 0: A stored [M,K] (lda >= K)      trans_a = 1: A stored [K,M] (lda >= M)
+ *   trans_b = 0: B stored [N,K] (ldb >= K)      trans_b = 1: B stored [K,N] (ldb >= N)
+ * so  nn.Linear forward  = (0,0) with B = weight[out,in]   (F.linear at base_transformer.py:35-41,
+ *     clip_fdt.py:86-92; in/out projections inside nn.MultiheadAttention, base_transformer.py:45-48)
+ *     its input gradient  = (0,1) with A = dY, B = weight
+ *     its weight gradient = (1,1) with A = dY, B = X, accumulate = 1.
+ * compute_dtype ILVLM_BF16: A,B bf16 -> v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+ * compute_dtype ILVLM_F32 : A,B f32  -> v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+ * Epilogue, in this order: acc *= alpha * (alpha_ptr ? *alpha_ptr : 1); += bias[n];
+ *   += rowbias[(out_skip + m % out_group) * N + n]; activation (see ILVLM_ACT_*; aux is [M,N] with
+ *   stride ldc, dtype = compute_dtype); += residual (fp32, laid out like C); store as out_dtype
+ *   (accumulate = 1: fp32 atomic add, no other epilogue term except alpha).
+ * out_group > 0 maps output row m to (m / out_group) * (out_group + out_skip) + out_skip + m % out_group
+ *   (patch tokens written behind the class token, visual_transformer.py:56-63).
+ * split_k >= 1 partitions K over that many workgroups per tile (requires accumulate = 1 if > 1).
+ * Alignment: bf16 operands need 16-byte aligned bases and lda/ldb multiples of 8; fp32 multiples of 4.
+ */
+typedef struct ilvlm_gemm_epilogue {
+    const float* bias;      /* [N] or NULL */
+    const float* rowbias;   /* [(out_group+out_skip), N] or NULL */
+    const float* residual;  /* fp32, same layout/stride as C, or NULL */
+    void* aux;              /* [M,N] stride ldc, compute dtype; written (ACT fwd) or read (ACT bwd) */
+    const float* alpha_ptr; /* device scalar or NULL */
+    float alpha;            /* host scalar (use 1.0f) */
+    int act;                /* ILVLM_ACT_* */
+    int out_dtype;          /* ILVLM_F32 / ILVLM_BF16 (bf16 only with compute_dtype bf16) */
+    int accumulate;         /* 0 store, 1 fp32 atomic += */
+    int out_group, out_skip;
+} ilvlm_gemm_epilogue;
+
+int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
+               const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm eps 1e-5 affine; base_transformer.py:10-18, clip_fdt.py:86-92) ----
+ * y[r,:] = (x[R,:] - mean) * rstd * gamma + beta, R = map(r) when in_group > 0 (row remap as above:
+ * the FDT image query reads patch tokens x[:,1:,:], visual_transformer.py:72).  mean/rstd: [rows]. */
+int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                        float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
+                        void* stream);
+/* dx = LN'(dy) [+ dres]; writes dx_f32 (fp32) and/or dx_lp (dtype dx_lp_dtype, optionally multiplied by
+ * act'(act_aux) for act in {ILVLM_ACT_QUICKGELU_BWD, ILVLM_ACT_GELU_ERF_BWD}); dgamma/dbeta "+=".
+ * x, dres, dx_f32, dx_lp use the remapped rows when group > 0; dy, mean, rstd, act_aux are compact. */
+int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                        const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
+                        int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
+                        int cols, int group, int skip, void* stream);
+
+/* ---- multi-head self attention core, head_dim 64 (F.multi_head_attention_forward math path reached
+ * from base_transformer.py:45-48 / text_encoder/base_transformer.py:45-48; additive causal mask
+ * text_transformer.py:147-153).  qkv: T [B*L, 3*64*H] rows = (b, l), columns = [q | k | v] each split
+ * into H heads of 64.  out: T [B*L, 64*H].  lse: fp32 [B, H, L] row log-sum-exp saved for backward
+ * (the reference materialises the [B*H, L, L] probabilities and their head mean; neither is needed). */
+int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
+                        void* stream);
+int ilvlm_attention_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv,
+                        int dtype, int B, int L, int H, int causal, void* stream);
+
+/* ---- token embedding + positional embedding (text_transformer.py:228-231) ---- */
+int ilvlm_embed_fwd(const int64_t* tokens, const float* table, const float* pos, float* x, int B, int L, int W,
+                    int vocab, void* stream);
+/* dtable[tokens[b,l],:] += dx[b,l,:];  dpos[l,:] += sum_b dx[b,l,:] */
+int ilvlm_embed_bwd(const int64_t* tokens, const float* dx, float* dtable, float* dpos, int B, int L, int W,
+                    int vocab, void* stream);
+
+/* ---- ViT patch embedding helpers (nn.Conv2d k=s=patch as an im2col GEMM, visual_transformer.py:56-63) ----
+ * patches[(b*g*g + py*g + px), c*ps*ps + ky*ps + kx] = images[b,c,py*ps+ky,px*ps+kx]  (T out) */
+int ilvlm_patchify(const float* images, void* patches, int dtype, int B, int C, int res, int ps, void* stream);
+/* tokens[b,0,:] = cls + pos[0,:]   (tokens: fp32 [B, L, W]) */
+int ilvlm_cls_rows(const float* cls, const float* pos, float* tokens, int B, int L, int W, void* stream);
+/* out[l,:] += sum_b x[b,l,:] (positional-embedding grad); out0[:] += sum_b x[b,0,:] if out0 (class embedding grad) */
+int ilvlm_batch_sum(const float* x, float* out, float* out0, int B, int L, int W, void* stream);
+/* gather / scatter of one row per batch element: y[b,:] = x[b, idx[b], :]; dx[b, idx[b], :] += dy[b,:] */
+int ilvlm_gather_rows(const float* x, const int64_t* idx, float* y, int B, int L, int W, void* stream);
+int ilvlm_scatter_rows(const float* dy, const int64_t* idx, float* dx, int B, int L, int W, void* stream);
+
+/* ---- FDT codebook attention (Query_model.forward, clip_fdt.py:113-145) ----
+ * scores: fp32 [B*T, C] = q @ sd^T.  v = ((s / sqrt_d) * (pad_mask[b,t] == 0)) / temperature;
+ * pooled[b,c] = max_t | mean_t | sum_t v;  argmax: int32 [B,C] (max only). */
+int ilvlm_fdt_pool_fwd(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T, int C,
+                       float sqrt_d, float temperature, int pool, void* stream);
+/* dscores[b,t,c] (dtype T) = dpooled[b,c] * d v / d s, routed to the argmax token for max pooling */
+int ilvlm_fdt_pool_bwd(const float* dpooled, const int* argmax, const float* pad_mask, void* dscores, int dtype,
+                       int B, int T, int C, float sqrt_d, float temperature, int pool, void* stream);
+
+/* ---- row-wise simplex maps over C codes (sparsemax.py:22-71; nn.Softmax clip_fdt.py:73-78) ---- */
+int ilvlm_sparsemax_fwd(const float* z, float* out, int rows, int cols, void* stream);
+int ilvlm_sparsemax_bwd(const float* out, const float* g, float* dz, int rows, int cols, void* stream);
+int ilvlm_softmax_fwd(const float* z, float* out, int rows, int cols, void* stream);
+int ilvlm_softmax_bwd(const float* out, const float* g, float* dz, int rows, int cols, void* stream);
+
+/* ---- y = x / (||x|| + eps) (clip_fdt.py:411-412; clip.py:133-134) ---- */
+int ilvlm_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream);
+int ilvlm_l2norm_bwd(const float* x, const float* norm, const float* dy, float* dx, int rows, int cols, float eps,
+                     void* stream);
+
+/* ---- temperature: out[0] = min(exp(logit_scale[0]), max_scale) (clip_fdt.py:415-416) ---- */
+int ilvlm_logit_scale_fwd(const float* logit_scale, float* out, float max_scale, void* stream);
+/* dparam[0] += (sum dli*li + sum dlt*lt) / scale_used * exp(param)   (d/d param of logits = scale * cos) */
+int ilvlm_logit_scale_bwd(const float* dli, const float* li, const float* dlt, const float* lt, long n,
+                          const float* logit_scale, const float* scale_used, float* dparam, void* stream);
+
+/* ---- InfoNCE (ClipInfoCELoss.forward, loss.py:37-47): labels[r] = label_offset + r.
+ * loss[0] = (CE(logits_i) + CE(logits_t)) / 2 (mean over B rows);
+ * dlogits_* = d loss / d logits_* = (softmax - onehot) / (2B). */
+int ilvlm_infonce_fwd(const float* logits_i, const float* logits_t, int B, int Bg, int label_offset, float* loss,
+                      float* dlogits_i, float* dlogits_t, void* stream);
+/* accuracy() of misc.py:464-477: out[0] = 100/B * #{rows whose label is in the top-1}, out[1] same for top-k */
+int ilvlm_topk_accuracy(const float* logits, int B, int Bg, int label_offset, int k, float* out, void* stream);
+
+/* ---- small utilities ---- */
+/* out[c] += sum_r x[r,c]  (bias gradients) */
+int ilvlm_colsum(const void* x, int dtype, float* out, long rows, int cols, int ld, void* stream);
+/* dst (dtype) = src (fp32): bf16 shadow of the fp32 master weights */
+int ilvlm_cast_f32(const float* src, void* dst, int dst_dtype, long n, void* stream);
+/* y = a * x (fp32, in place allowed) */
+int ilvlm_scale(const float* x, float* y, float a, long n, void* stream);
+
+/* ---- fused multi-tensor AdamW (torch.optim.AdamW semantics, optimizer/__init__.py:3,18-26).
+ * The parameters live in one flat fp32 arena; `chunk_*` arrays (device) describe n_chunks pieces:
+ * element offset, element count and param-group id of each; lr/wd are per group (<= 16 groups).
+ * active[group] == 0 skips the group entirely (parameters without gradient are not touched).
+ * shadow (optional, bf16) receives the updated parameters. step is 1-based. */
+typedef struct ilvlm_adamw_hyper {
+    float lr[16];
+    float weight_decay[16];
+    int active[16];
+    float beta1, beta2, eps;
+    int step;
+} ilvlm_adamw_hyper;
+int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                     const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
+                     int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream);
+
+/* ---- self tests of the MFMA / LDS-transpose fragment maps (used by tests only) ---- */
+int ilvlm_selftest_fragments(float* out /* [5][64][8] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILVLM_HIP_H */

@@ -1,0 +1,52 @@
+// Fused multi-tensor AdamW over a flat fp32 parameter arena (decoupled weight decay, amsgrad off): one launch
+// for all ~320 tensors, 28 B/param of HBM traffic (+2 B for the bf16 shadow the GEMMs consume).
+// torch.optim.AdamW semantics as selected by the reference (prototype/optimizer/__init__.py:3,18-26;
+// hyper-parameters example/clip_fdt/config_cc3m.yaml:34-41):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+#include "common.h"
+
+namespace {
+
+constexpr int CHUNK = 4096;   // elements per workgroup-chunk (16 per thread)
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ shadow,
+                                                    const int64_t* __restrict__ coff, const int32_t* __restrict__ ccnt,
+                                                    const int32_t* __restrict__ cgrp, ilvlm_adamw_hyper h, float bc1,
+                                                    float bc2_sqrt) {
+    const int ch = blockIdx.x;
+    const int grp = cgrp[ch];
+    if (!h.active[grp]) return;
+    const long off = coff[ch];
+    const int n = ccnt[ch];
+    const float lr = h.lr[grp], wd = h.weight_decay[grp];
+    const float decay = 1.f - lr * wd, step_size = lr / bc1;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const long k = off + i;
+        float gk = g[k], pk = p[k] * decay;
+        float mk = h.beta1 * m[k] + (1.f - h.beta1) * gk;
+        float vk = h.beta2 * v[k] + (1.f - h.beta2) * gk * gk;
+        m[k] = mk;
+        v[k] = vk;
+        pk -= step_size * mk / (sqrtf(vk) / bc2_sqrt + h.eps);
+        p[k] = pk;
+        if (shadow) shadow[k] = (bf16)pk;
+    }
+}
+
+}  // namespace
+
+extern "C" int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
+                                int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream) {
+    ILVLM_REQUIRE(params && grads && exp_avg && exp_avg_sq && chunk_offset && chunk_count && chunk_group && hyper,
+                  "adamw_step: null pointer");
+    ILVLM_REQUIRE(n_chunks > 0 && hyper->step >= 1, "adamw_step: bad n_chunks / step");
+    const double bc1 = 1.0 - pow((double)hyper->beta1, (double)hyper->step);
+    const double bc2 = 1.0 - pow((double)hyper->beta2, (double)hyper->step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       (bf16*)shadow_bf16, chunk_offset, chunk_count, chunk_group, *hyper, (float)bc1, (float)sqrt(bc2));
+    ILVLM_LAUNCH_CHECK("adamw_step");
+    return ILVLM_OK;
+}

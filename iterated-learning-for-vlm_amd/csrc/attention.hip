@@ -1,0 +1,440 @@
+// Self-attention core for short sequences (L <= 128, head_dim 64): one workgroup per (batch, head), the whole
+// L x L problem resident in LDS.  bf16 path: all five products on v_mfma_f32_16x16x32_bf16, K-strided operands
+// fetched with ds_read_b64_tr_b16 (no transposed copies), fp32 softmax with 16-lane shuffle reductions, only the
+// row log-sum-exp is saved for backward (probabilities are recomputed).  fp32 path: plain VALU kernel used by
+// the fp32 parity mode.
+// Replaces the bmm/baddbmm -> softmax -> bmm sequence of F.multi_head_attention_forward reached from reference
+// image_encoder/base_transformer.py:45-48 and text_encoder/base_transformer.py:45-48 (causal mask
+// text_transformer.py:147-153).  The reference's head-averaged attention weights are discarded by its callers
+// (base_transformer.py:59, text_transformer.py:234 unless return_att) and are not produced.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int LDH = HD + 8;   // [rows][72] bf16 images of Q, K, V, dO (144-byte rows)
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// operand stored [rows][k] (k contiguous): lane l gets [r16 + (l&15)][k32 + 8*(l>>4) + j]
+__device__ __forceinline__ bf16x8 frag_k(const bf16* base, int ld, int r16, int k32, int lane) {
+    return *(const bf16x8*)(base + (r16 + (lane & 15)) * ld + k32 + 8 * (lane >> 4));
+}
+// operand stored [k][cols] (cols contiguous): lane l gets [k32 + 8*(l>>4) + j][c16 + (l&15)]
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* base, int ld, int k32, int c16, int lane) {
+    int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+    const bf16* a = base + (k32 + 8 * g + q) * ld + c16 + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * ld));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+// load [L][64] slice (column offset coff of the packed qkv / out rows) into an [LP][72] LDS image, zero padded
+template <int LP>
+__device__ __forceinline__ void load_rows(bf16* dst, const bf16* src, long row_stride, int L, float scale, int tid) {
+    for (int c = tid; c < LP * 8; c += 256) {
+        int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < L) {
+            v = *(const bf16x8*)(src + r * row_stride + ch * 8);
+            if (scale != 1.0f)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * scale);
+        }
+        *(bf16x8*)(dst + r * LDH + ch * 8) = v;
+    }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                     float* __restrict__ lse, int L, int H, int causal) {
+    constexpr int NT = LP / 16, LDP = LP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Qs = (bf16*)smem_raw;
+    bf16* Ks = Qs + LP * LDH;
+    bf16* Vt = Ks + LP * LDH;          // [64][LDP]  (V transposed)
+    bf16* Ps = Vt + HD * LDP;          // [LP][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
+    load_rows<LP>(Ks, base + E, rs, L, 1.0f, tid);
+    for (int c = tid; c < LP * 8; c += 256) {
+        int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < L) v = *(const bf16x8*)(base + 2 * E + r * rs + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * LDP + r] = v[j];
+    }
+    __syncthreads();
+
+    const int nqt = (L + 15) / 16;
+    const int g = lane >> 4, c16 = lane & 15;
+    for (int it = 0; it * 4 < nqt; ++it) {
+        const int qt = it * 4 + wave;
+        const bool active = qt < nqt;   // wave-uniform
+        if (active) {
+            f32x4 s[NT];
+            bf16x8 qa0 = frag_k(Qs, LDH, qt * 16, 0, lane), qa1 = frag_k(Qs, LDH, qt * 16, 32, lane);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 a = {0, 0, 0, 0};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(Ks, LDH, kt * 16, 0, lane), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(Ks, LDH, kt * 16, 32, lane), a, 0, 0, 0);
+                s[kt] = a;   // s[kt][r] = S[q = qt*16 + 4g + r][key = kt*16 + c16]
+            }
+            float mx[4], sm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const int key = kt * 16 + c16;
+                    const bool ok = key < L && (!causal || key <= q);
+                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    m = fmaxf(m, s[kt][r]);
+                }
+                m = group16_max(m);
+                float t = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    float e = __expf(s[kt][r] - m);
+                    s[kt][r] = e;
+                    t += e;
+                }
+                t = group16_sum(t);
+                mx[r] = m; sm[r] = t;
+                const float inv = 1.0f / t;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) Ps[(qt * 16 + 4 * g + r) * LDP + kt * 16 + c16] = (bf16)(s[kt][r] * inv);
+                if (c16 == 0 && q < L) lse[((long)b * H + h) * L + q] = m + __logf(t);
+            }
+            (void)mx; (void)sm;
+        }
+        __syncthreads();   // P rows of this round visible (each wave only re-reads its own rows)
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < LP / 32; ++ks)   // D[d][q] = sum_key Vt[d][key] * P[q][key]
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Vt, LDP, dt * 16, ks * 32, lane),
+                                                                frag_k(Ps, LDP, qt * 16, ks * 32, lane), o, 0, 0, 0);
+                const int q = qt * 16 + c16;
+                if (q < L) {
+                    bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                    *(bf16x4*)(out + ((long)b * L + q) * E + h * HD + dt * 16 + 4 * g) = ov;
+                }
+            }
+        }
+    }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
+                                                     const bf16* __restrict__ outp, const float* __restrict__ lse,
+                                                     bf16* __restrict__ dqkv, int L, int H, int causal) {
+    constexpr int NT = LP / 16, LDP = LP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Qs = (bf16*)smem_raw;
+    bf16* Ks = Qs + LP * LDH;
+    bf16* Vs = Ks + LP * LDH;
+    bf16* dOs = Vs + LP * LDH;
+    bf16* Ps = dOs + LP * LDH;         // [LP][LDP]
+    bf16* dSs = Ps + LP * LDP;         // [LP][LDP]
+    float* delta = (float*)(dSs + LP * LDP);
+    float* lses = delta + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
+    load_rows<LP>(Ks, base + E, rs, L, 1.0f, tid);
+    load_rows<LP>(Vs, base + 2 * E, rs, L, 1.0f, tid);
+    const bf16* dob = dout + (long)b * L * E + h * HD;
+    const bf16* ob = outp + (long)b * L * E + h * HD;
+    for (int c = tid; c < LP * 8; c += 256) {   // LP*8 is a multiple of 256: every lane participates in the shuffles
+        int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        float part = 0.f;
+        if (r < L) {
+            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
+            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
+        }
+        *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (ch == 0) delta[r] = part;
+    }
+    for (int r = tid; r < LP; r += 256) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
+    __syncthreads();
+
+    const int g = lane >> 4, c16 = lane & 15;
+    // phase 1: P and dS for every 16-row query tile (all NT tiles so the padded rows are written as zeros)
+    for (int qt = wave; qt < NT; qt += 4) {
+        bf16x8 qa0 = frag_k(Qs, LDH, qt * 16, 0, lane), qa1 = frag_k(Qs, LDH, qt * 16, 32, lane);
+        bf16x8 da0 = frag_k(dOs, LDH, qt * 16, 0, lane), da1 = frag_k(dOs, LDH, qt * 16, 32, lane);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(Ks, LDH, kt * 16, 0, lane), s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(Ks, LDH, kt * 16, 32, lane), s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, frag_k(Vs, LDH, kt * 16, 0, lane), dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, frag_k(Vs, LDH, kt * 16, 32, lane), dp, 0, 0, 0);
+            const int key = kt * 16 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                const bool ok = q < L && key < L && (!causal || key <= q);
+                float p = ok ? __expf(s[r] - lses[q]) : 0.f;
+                float ds = p * (dp[r] - delta[q]);
+                Ps[q * LDP + key] = (bf16)p;
+                dSs[q * LDP + key] = (bf16)ds;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: dV = P^T dO, dK = dS^T (Q/8), dQ = (dS K)/8 ; 3 * NT * 4 independent 16x16 output tiles
+    for (int job = wave; job < 3 * NT * 4; job += 4) {
+        const int which = job / (NT * 4), rt = (job >> 2) % NT, dt = job & 3;
+        f32x4 acc = {0, 0, 0, 0};
+        if (which == 2) {          // dQ[q][d]: D[d][q] = sum_key K[key][d] * dS[q][key]
+#pragma unroll
+            for (int ks = 0; ks < LP / 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, LDH, ks * 32, dt * 16, lane),
+                                                              frag_k(dSs, LDP, rt * 16, ks * 32, lane), acc, 0, 0, 0);
+            acc *= 0.125f;
+        } else {                   // dV / dK [key][d]: D[d][key] = sum_q X[q][d] * Y[q][key]
+            const bf16* X = which == 0 ? dOs : Qs;
+            const bf16* Y = which == 0 ? Ps : dSs;
+#pragma unroll
+            for (int ks = 0; ks < LP / 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(X, LDH, ks * 32, dt * 16, lane),
+                                                              frag_tr(Y, LDP, ks * 32, rt * 16, lane), acc, 0, 0, 0);
+        }
+        const int row = rt * 16 + c16;
+        if (row < L) {
+            const int coff = which == 2 ? 0 : (which == 1 ? E : 2 * E);
+            bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
+            *(bf16x4*)(dqkv + ((long)b * L + row) * rs + coff + h * HD + dt * 16 + 4 * g) = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 VALU kernels (parity mode; L <= 96 forward, L <= 80 backward)
+// ---------------------------------------------------------------------------------------------
+constexpr int LDF = HD + 1;
+
+__device__ __forceinline__ void load_rows_f32(float* dst, const float* src, long row_stride, int L, float scale, int tid) {
+    for (int i = tid; i < L * HD; i += 256) {
+        int r = i >> 6, d = i & 63;
+        dst[r * LDF + d] = src[r * row_stride + d] * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                    float* __restrict__ lse, int L, int H, int causal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* Qs = (float*)smem_raw;
+    float* Ks = Qs + L * LDF;
+    float* Vs = Ks + L * LDF;
+    float* S = Vs + L * LDF;   // [L][L+1]
+    const int LS = L + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const float* base = qkv + (long)b * L * rs + h * HD;
+    load_rows_f32(Qs, base, rs, L, 0.125f, tid);
+    load_rows_f32(Ks, base + E, rs, L, 1.0f, tid);
+    load_rows_f32(Vs, base + 2 * E, rs, L, 1.0f, tid);
+    __syncthreads();
+    for (int i = tid; i < L * L; i += 256) {
+        int q = i / L, k = i % L;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < HD; ++d) s = fmaf(Qs[q * LDF + d], Ks[k * LDF + d], s);
+        S[q * LS + k] = (causal && k > q) ? -INFINITY : s;
+    }
+    __syncthreads();
+    for (int q = wave; q < L; q += 4) {
+        float m = -INFINITY;
+        for (int k = lane; k < L; k += 64) m = fmaxf(m, S[q * LS + k]);
+        m = wave_max(m);
+        float t = 0.f;
+        for (int k = lane; k < L; k += 64) t += __expf(S[q * LS + k] - m);
+        t = wave_sum(t);
+        for (int k = lane; k < L; k += 64) S[q * LS + k] = __expf(S[q * LS + k] - m) / t;
+        if (lane == 0) lse[((long)b * H + h) * L + q] = m + __logf(t);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * HD; i += 256) {
+        int q = i >> 6, d = i & 63;
+        float o = 0.f;
+        for (int k = 0; k < L; ++k) o = fmaf(S[q * LS + k], Vs[k * LDF + d], o);
+        out[((long)b * L + q) * E + h * HD + d] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                    const float* __restrict__ outp, const float* __restrict__ lse,
+                                                    float* __restrict__ dqkv, int L, int H, int causal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* Qs = (float*)smem_raw;
+    float* Ks = Qs + L * LDF;
+    float* Vs = Ks + L * LDF;
+    float* dOs = Vs + L * LDF;
+    float* P = dOs + L * LDF;      // [L][L+1]
+    const int LS = L + 1;
+    float* dS = P + L * LS;        // [L][L+1]
+    float* delta = dS + L * LS;    // [L]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const float* base = qkv + (long)b * L * rs + h * HD;
+    load_rows_f32(Qs, base, rs, L, 0.125f, tid);
+    load_rows_f32(Ks, base + E, rs, L, 1.0f, tid);
+    load_rows_f32(Vs, base + 2 * E, rs, L, 1.0f, tid);
+    const float* dob = dout + (long)b * L * E + h * HD;
+    const float* ob = outp + (long)b * L * E + h * HD;
+    load_rows_f32(dOs, dob, E, L, 1.0f, tid);
+    for (int q = wave; q < L; q += 4) {
+        float t = dob[(long)q * E + lane] * ob[(long)q * E + lane];
+        t = wave_sum(t);
+        if (lane == 0) delta[q] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * L; i += 256) {
+        int q = i / L, k = i % L;
+        float s = 0.f, dp = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < HD; ++d) {
+            s = fmaf(Qs[q * LDF + d], Ks[k * LDF + d], s);
+            dp = fmaf(dOs[q * LDF + d], Vs[k * LDF + d], dp);
+        }
+        float p = (causal && k > q) ? 0.f : __expf(s - lse[((long)b * H + h) * L + q]);
+        P[q * LS + k] = p;
+        dS[q * LS + k] = p * (dp - delta[q]);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * HD; i += 256) {
+        int r = i >> 6, d = i & 63;
+        float dv = 0.f, dk = 0.f, dq = 0.f;
+        for (int j = 0; j < L; ++j) {
+            dv = fmaf(P[j * LS + r], dOs[j * LDF + d], dv);
+            dk = fmaf(dS[j * LS + r], Qs[j * LDF + d], dk);
+            dq = fmaf(dS[r * LS + j], Ks[j * LDF + d], dq);
+        }
+        float* o = dqkv + ((long)b * L + r) * rs + h * HD + d;
+        o[0] = dq * 0.125f;
+        o[E] = dk;
+        o[2 * E] = dv;
+    }
+}
+
+template <class K>
+int set_lds(K kern, int bytes, const char* name) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) ILVLM_FAIL((int)e, "%s: hipFuncSetAttribute(%d): %s", name, bytes, hipGetErrorString(e));
+    return ILVLM_OK;
+}
+
+template <int LP>
+int launch_fwd_bf16(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, hipStream_t s) {
+    constexpr int LDP = LP + 8;
+    constexpr int bytes = (2 * LP * LDH + HD * LDP + LP * LDP) * 2;
+    static bool done = false;   // per instantiation; the attribute is idempotent
+    if (!done) {
+        int rc = set_lds(attn_fwd_bf16<LP>, bytes, "attention_fwd");
+        if (rc) return rc;
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_bf16<LP>), dim3(B * H), dim3(256), bytes, s, qkv, out, lse, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_fwd");
+    return ILVLM_OK;
+}
+template <int LP>
+int launch_bwd_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
+                    int causal, hipStream_t s) {
+    constexpr int LDP = LP + 8;
+    constexpr int bytes = (4 * LP * LDH + 2 * LP * LDP) * 2 + 2 * LP * 4;
+    static bool done = false;
+    if (!done) {
+        int rc = set_lds(attn_bwd_bf16<LP>, bytes, "attention_bwd");
+        if (rc) return rc;
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_bwd");
+    return ILVLM_OK;
+}
+
+}  // namespace
+
+extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
+                                   void* stream) {
+    ILVLM_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
+    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_fwd: bad shape B=%d L=%d H=%d", B, L, H);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ILVLM_BF16) {
+        ILVLM_REQUIRE(L <= 128, "attention_fwd(bf16): L=%d > 128 not supported yet", L);
+        const bf16* q = (const bf16*)qkv;
+        bf16* o = (bf16*)out;
+        if (L <= 32) return launch_fwd_bf16<32>(q, o, lse, B, L, H, causal, s);
+        if (L <= 64) return launch_fwd_bf16<64>(q, o, lse, B, L, H, causal, s);
+        if (L <= 96) return launch_fwd_bf16<96>(q, o, lse, B, L, H, causal, s);
+        return launch_fwd_bf16<128>(q, o, lse, B, L, H, causal, s);
+    }
+    ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_fwd: bad dtype %d", dtype);
+    ILVLM_REQUIRE(L <= 96, "attention_fwd(f32): L=%d > 96 not supported", L);
+    int bytes = (3 * L * LDF + L * (L + 1)) * 4;
+    static bool done_f = false;
+    if (!done_f) {
+        int rc = set_lds(attn_fwd_f32, 160 * 1024, "attention_fwd_f32");
+        if (rc) return rc;
+        done_f = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)qkv, (float*)out, lse, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_fwd_f32");
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv,
+                                   int dtype, int B, int L, int H, int causal, void* stream) {
+    ILVLM_REQUIRE(dout && qkv && out && lse && dqkv, "attention_bwd: null pointer");
+    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_bwd: bad shape B=%d L=%d H=%d", B, L, H);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ILVLM_BF16) {
+        ILVLM_REQUIRE(L <= 128, "attention_bwd(bf16): L=%d > 128 not supported yet", L);
+        const bf16 *d = (const bf16*)dout, *q = (const bf16*)qkv, *o = (const bf16*)out;
+        bf16* dq = (bf16*)dqkv;
+        if (L <= 32) return launch_bwd_bf16<32>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 64) return launch_bwd_bf16<64>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 96) return launch_bwd_bf16<96>(d, q, o, lse, dq, B, L, H, causal, s);
+        return launch_bwd_bf16<128>(d, q, o, lse, dq, B, L, H, causal, s);
+    }
+    ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_bwd: bad dtype %d", dtype);
+    ILVLM_REQUIRE(L <= 80, "attention_bwd(f32): L=%d > 80 not supported", L);
+    int bytes = (4 * L * LDF + 2 * L * (L + 1) + L) * 4;
+    static bool done_b = false;
+    if (!done_b) {
+        int rc = set_lds(attn_bwd_f32, 160 * 1024, "attention_bwd_f32");
+        if (rc) return rc;
+        done_b = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)dout, (const float*)qkv,
+                       (const float*)out, lse, (float*)dqkv, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_bwd_f32");
+    return ILVLM_OK;
+}

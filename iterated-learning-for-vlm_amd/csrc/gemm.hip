@@ -1,0 +1,436 @@
+// GEMM with fused epilogues for gfx950.
+//   bf16 path : 128x128x64 tile, 4 waves (2x2) each 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles,
+//               double-buffered LDS, next K-tile's global loads in flight during the MFMA phase,
+//               K-contiguous operands read with ds_read_b128, K-strided ("transposed") operands read
+//               with ds_read_b64_tr_b16, so dgrad / wgrad need no transposed copies of weights or
+//               activations.  XCD-aware block remap so one XCD's L2 sees neighbouring tiles.
+//   fp32 path : 64x64x16 tile on v_mfma_f32_16x16x4_f32 (bit-exact fp32 FMA chain) for the fp32
+//               parity mode and the small precision-critical products (att@sd, logits).
+// Replaces F.linear / matmul call sites listed in include/ilvlm_hip.h.
+#include "common.h"
+
+namespace {
+
+struct EpiArgs {
+    ilvlm_gemm_epilogue e;
+    float* Cf;     // fp32 view of C
+    bf16* Cb;      // bf16 view of C
+    int ldc;
+    int M, N;
+    int vec_ok;    // N%4==0 && ldc%4==0 and all pointers 16B aligned
+};
+
+// Handles 4 consecutive columns [n, n+4) of output row m.  AuxT = compute dtype.
+template <class AuxT>
+__device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 v, float alpha) {
+    if (m >= a.M || n >= a.N) return;
+    const ilvlm_gemm_epilogue& e = a.e;
+    long orow = map_row(m, e.out_group, e.out_skip);
+    long off = orow * (long)a.ldc + n;
+    const bool full = a.vec_ok && (n + 4 <= a.N);
+    v *= alpha;
+    if (e.accumulate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) atomicAdd(a.Cf + off + i, v[i]);
+        return;
+    }
+    if (full) {
+        if (e.bias) v += *(const f32x4*)(e.bias + n);
+        if (e.rowbias) v += *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * a.N + n);
+        if (e.act) {
+            AuxT* aux = (AuxT*)e.aux + off;
+            if (e.act == ILVLM_ACT_QUICKGELU || e.act == ILVLM_ACT_GELU_ERF) {
+                store4<AuxT>(aux, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = e.act == ILVLM_ACT_QUICKGELU ? quick_gelu(v[i]) : gelu_erf(v[i]);
+            } else {
+                f32x4 u = load4<AuxT>(aux);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] *= e.act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(u[i]) : gelu_erf_grad(u[i]);
+            }
+        }
+        if (e.residual) v += *(const f32x4*)(e.residual + off);
+        if (e.out_dtype == ILVLM_F32) store4<float>(a.Cf + off, v);
+        else store4<bf16>(a.Cb + off, v);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (n + i >= a.N) break;
+        float x = v[i];
+        if (e.bias) x += e.bias[n + i];
+        if (e.rowbias) x += e.rowbias[(long)(e.out_skip + m % e.out_group) * a.N + n + i];
+        if (e.act) {
+            AuxT* aux = (AuxT*)e.aux + off + i;
+            if (e.act == ILVLM_ACT_QUICKGELU) { *aux = from_f<AuxT>(x); x = quick_gelu(x); }
+            else if (e.act == ILVLM_ACT_GELU_ERF) { *aux = from_f<AuxT>(x); x = gelu_erf(x); }
+            else if (e.act == ILVLM_ACT_QUICKGELU_BWD) x *= quick_gelu_grad(to_f<AuxT>(*aux));
+            else x *= gelu_erf_grad(to_f<AuxT>(*aux));
+        }
+        if (e.residual) x += e.residual[off + i];
+        if (e.out_dtype == ILVLM_F32) a.Cf[off + i] = x;
+        else a.Cb[off + i] = (bf16)x;
+    }
+}
+
+// XCD-aware bijective remap (blocks b and b+8 share an XCD; give each XCD a contiguous tile range)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// =====================================================================================
+// bf16 kernel
+// =====================================================================================
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDK = BK + 8;    // K-contiguous image: [128 rows][72]   (144-byte rows)
+constexpr int LDT = 128 + 8;   // K-strided   image: [64 k][136]       (272-byte rows)
+constexpr int TILE_ELEMS = 128 * LDK;   // 9216 >= 64*136 = 8704
+constexpr int GEMM_LDS_BYTES = 4 * TILE_ELEMS * 2;   // A,B x 2 buffers = 73728
+
+struct Stage {   // one operand tile's worth of global loads held in registers: 4 x 16 bytes per thread
+    bf16x8 v[4];
+};
+
+// Load an operand tile (rows [r0, r0+128) x k [k0, k0+64)) into registers.
+// TR = false: source is [R, K] with K contiguous.  TR = true: source is [K, R] with R contiguous.
+template <bool TR>
+__device__ __forceinline__ void stage_load(Stage& s, const bf16* __restrict__ src, int ld, int r0, int k0, int R, int Kend,
+                                           int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i;
+        int row, col, rlim, clim;
+        long goff;
+        if (!TR) {
+            row = r0 + (c >> 3);           // operand row
+            col = k0 + (c & 7) * 8;        // k
+            rlim = R; clim = Kend;
+            goff = (long)row * ld + col;
+        } else {
+            row = k0 + (c >> 4);           // k
+            col = r0 + (c & 15) * 8;       // operand row (contiguous)
+            rlim = Kend; clim = R;
+            goff = (long)row * ld + col;
+        }
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < rlim) {
+            if (col + 8 <= clim) {
+                v = *(const bf16x8*)(src + goff);
+            } else {
+                for (int j = 0; j < 8; ++j)
+                    if (col + j < clim) v[j] = src[goff + j];
+            }
+        }
+        s.v[i] = v;
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void stage_store(const Stage& s, bf16* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i;
+        int off = !TR ? (c >> 3) * LDK + (c & 7) * 8 : (c >> 4) * LDT + (c & 15) * 8;
+        *(bf16x8*)(lds + off) = s.v[i];
+    }
+}
+
+// fragment of 16 operand rows starting at row r16 for the 32-deep k-substep starting at k32.
+// lane l holds operand[r16 + (l&15)][k32 + 8*(l>>4) + j], j = 0..7.
+template <bool TR>
+__device__ __forceinline__ bf16x8 load_frag(const bf16* lds, int r16, int k32, int lane) {
+    if (!TR) {
+        return *(const bf16x8*)(lds + (r16 + (lane & 15)) * LDK + k32 + 8 * (lane >> 4));
+    } else {
+        // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+        // 4x16 block; lane i receives column i of the 4 rows.  Two blocks (k 0-3 and 4-7 of this lane group's 8 k).
+        int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+        const bf16* base = lds + (k32 + 8 * g + q) * LDT + r16 + 4 * p;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LDT));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        return u.v;
+    }
+}
+
+// SWAP = true : acc tile holds C^T fragments -> each lane owns 4 consecutive columns n (vector epilogue)
+// SWAP = false: each lane owns 4 consecutive rows m, lanes 0..15 span 16 contiguous n (atomic accumulate shape)
+template <bool TA, bool TB, bool SWAP>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                        int ldb, int K, int tiles_m, int tiles_n, int split_k,
+                                                        EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* smem = (bf16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = tiles_m * tiles_n * split_k;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int z = wg % split_k; wg /= split_k;
+    const int tn = wg % tiles_n, tm = wg / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nt_total = (K + BK - 1) / BK;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per;
+    const int t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;   // uniform per block
+    const int Kend = min(K, t_end * BK);
+
+    bf16* As[2] = {smem, smem + 2 * TILE_ELEMS};
+    bf16* Bs[2] = {smem + TILE_ELEMS, smem + 3 * TILE_ELEMS};
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+    Stage sa, sb;
+    stage_load<TA>(sa, A, lda, m0, t_begin * BK, ep.M, Kend, tid);
+    stage_load<TB>(sb, B, ldb, n0, t_begin * BK, ep.N, Kend, tid);
+    stage_store<TA>(sa, As[0], tid);
+    stage_store<TB>(sb, Bs[0], tid);
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = (t + 1 < t_end);
+        if (more) {
+            stage_load<TA>(sa, A, lda, m0, (t + 1) * BK, ep.M, Kend, tid);
+            stage_load<TB>(sb, B, ldb, n0, (t + 1) * BK, ep.N, Kend, tid);
+        }
+        const bf16* as = As[cur];
+        const bf16* bs = Bs[cur];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag<TA>(as, wm * 64 + i * 16, ks * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = load_frag<TB>(bs, wn * 64 + j * 16, ks * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            stage_store<TA>(sa, As[cur ^ 1], tid);
+            stage_store<TB>(sb, Bs[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (SWAP) {
+                // D[n_local = 4g + r][m_local = c]
+                int m = m0 + wm * 64 + i * 16 + c;
+                int n = n0 + wn * 64 + j * 16 + 4 * g;
+                epilogue4<bf16>(ep, m, n, acc[i][j], alpha);
+            } else {
+                // D[m_local = 4g + r][n_local = c] : only used with accumulate (scalar atomics)
+                int n = n0 + wn * 64 + j * 16 + c;
+                if (n < ep.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                        if (m < ep.M) {
+                            long off = map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n;
+                            atomicAdd(ep.Cf + off, acc[i][j][r] * alpha);
+                        }
+                    }
+                }
+            }
+        }
+}
+
+// =====================================================================================
+// fp32 kernel: 64x64x16 tile, 4 waves (2x2), each 32x32 = 2x2 tiles of 16x16x4
+// =====================================================================================
+constexpr int FM = 64, FN = 64, FK = 16, FLD = 68;
+
+// LDS image is [k][rows] (rows contiguous, padded): fragment lane l reads [kk + (l>>4)][r16 + (l&15)]
+template <bool TR>
+__device__ __forceinline__ void f32_stage(const float* __restrict__ src, int ld, int r0, int k0, int R, int Kend, float* lds,
+                                          int tid) {
+    if (!TR) {
+        // source [R, K]: thread -> row tid>>2, 4 consecutive k
+        int row = r0 + (tid >> 2), kc = (tid & 3) * 4, k = k0 + kc;
+        f32x4 v = {0, 0, 0, 0};
+        if (row < R) {
+            const float* p = src + (long)row * ld + k;
+            if (k + 4 <= Kend) v = *(const f32x4*)p;
+            else
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < Kend) v[j] = p[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[(kc + j) * FLD + (tid >> 2)] = v[j];
+    } else {
+        // source [K, R]: thread -> k tid>>4, 4 consecutive rows
+        int k = k0 + (tid >> 4), rc = (tid & 15) * 4, row = r0 + rc;
+        f32x4 v = {0, 0, 0, 0};
+        if (k < Kend) {
+            const float* p = src + (long)k * ld + row;
+            if (row + 4 <= R) v = *(const f32x4*)p;
+            else
+                for (int j = 0; j < 4; ++j)
+                    if (row + j < R) v[j] = p[j];
+        }
+        *(f32x4*)(lds + (tid >> 4) * FLD + rc) = v;
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
+    __shared__ __attribute__((aligned(16))) float As[FK * FLD];
+    __shared__ __attribute__((aligned(16))) float Bs[FK * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int wg = blockIdx.x;
+    const int z = wg % split_k; wg /= split_k;
+    const int tn = wg % tiles_n, tm = wg / tiles_n;
+    const int m0 = tm * FM, n0 = tn * FN;
+    const int nt_total = (K + FK - 1) / FK;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;
+    const int Kend = min(K, t_end * FK);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+    for (int t = t_begin; t < t_end; ++t) {
+        f32_stage<TA>(A, lda, m0, t * FK, ep.M, Kend, As, tid);
+        f32_stage<TB>(B, ldb, n0, t * FK, ep.N, Kend, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < FK; kk += 4) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = As[(kk + (lane >> 4)) * FLD + wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[(kk + (lane >> 4)) * FLD + wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);   // C^T fragments
+        }
+        __syncthreads();
+    }
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            epilogue4<float>(ep, m0 + wm * 32 + i * 16 + c, n0 + wn * 32 + j * 16 + 4 * g, acc[i][j], alpha);
+}
+
+template <bool TA, bool TB, bool SWAP>
+int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
+                hipStream_t s) {
+    auto kern = gemm_bf16_kernel<TA, TB, SWAP>;
+    static bool attr_set = false;   // idempotent; a benign race sets it twice
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(256), GEMM_LDS_BYTES, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16");
+    return ILVLM_OK;
+}
+
+template <bool TA, bool TB>
+int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
+               hipStream_t s) {
+    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), dim3(tm * tn * split_k), dim3(256), 0, s, A, lda, B, ldb, K, tm, tn,
+                       split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_f32");
+    return ILVLM_OK;
+}
+
+inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace
+
+extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
+                          const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k,
+                          void* stream) {
+    ILVLM_REQUIRE(A && B && C && epi, "gemm: null pointer");
+    ILVLM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    ILVLM_REQUIRE(compute_dtype == ILVLM_F32 || compute_dtype == ILVLM_BF16, "gemm: bad compute dtype %d", compute_dtype);
+    ILVLM_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? N : K) && ldc >= N, "gemm: leading dimension too small");
+    ILVLM_REQUIRE(split_k >= 1, "gemm: split_k must be >= 1");
+    ILVLM_REQUIRE(split_k == 1 || epi->accumulate, "gemm: split_k > 1 needs accumulate");
+    ILVLM_REQUIRE(!(epi->accumulate && (epi->bias || epi->rowbias || epi->residual || epi->act)),
+                  "gemm: accumulate excludes the other epilogue terms");
+    ILVLM_REQUIRE(!(epi->accumulate && epi->out_dtype != ILVLM_F32), "gemm: accumulate needs fp32 output");
+    ILVLM_REQUIRE(!(compute_dtype == ILVLM_F32 && epi->out_dtype != ILVLM_F32), "gemm: fp32 compute writes fp32");
+    ILVLM_REQUIRE(!(epi->act && !epi->aux), "gemm: activation needs aux");
+    ILVLM_REQUIRE(!(epi->rowbias && epi->out_group <= 0), "gemm: rowbias needs out_group");
+    ILVLM_REQUIRE(epi->act >= 0 && epi->act <= ILVLM_ACT_GELU_ERF_BWD, "gemm: bad act %d", epi->act);
+    hipStream_t s = (hipStream_t)stream;
+    EpiArgs ep;
+    ep.e = *epi;
+    ep.Cf = (float*)C;
+    ep.Cb = (bf16*)C;
+    ep.ldc = ldc;
+    ep.M = M;
+    ep.N = N;
+    size_t caln = epi->out_dtype == ILVLM_F32 ? 16 : 8;
+    size_t auxaln = compute_dtype == ILVLM_F32 ? 16 : 8;
+    ep.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && aligned(C, caln) && (!epi->bias || aligned(epi->bias, 16)) &&
+                (!epi->rowbias || aligned(epi->rowbias, 16)) && (!epi->residual || aligned(epi->residual, 16)) &&
+                (!epi->aux || aligned(epi->aux, auxaln));
+    if (compute_dtype == ILVLM_BF16) {
+        ILVLM_REQUIRE(aligned(A, 16) && aligned(B, 16) && lda % 8 == 0 && ldb % 8 == 0,
+                      "gemm bf16: operands need 16-byte alignment and lda/ldb %% 8 == 0 (lda=%d ldb=%d)", lda, ldb);
+        int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
+        int nt = ceil_div(K, BK);
+        if (split_k > nt) split_k = nt;
+        const bf16* a = (const bf16*)A;
+        const bf16* b = (const bf16*)B;
+        const bool swap = !epi->accumulate;
+#define ILVLM_DISPATCH(TA, TB)                                                                       \
+    return swap ? launch_bf16<TA, TB, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)               \
+                : launch_bf16<TA, TB, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)
+        if (!trans_a && !trans_b) { ILVLM_DISPATCH(false, false); }
+        if (!trans_a && trans_b) { ILVLM_DISPATCH(false, true); }
+        if (trans_a && !trans_b) { ILVLM_DISPATCH(true, false); }
+        ILVLM_DISPATCH(true, true);
+#undef ILVLM_DISPATCH
+    }
+    ILVLM_REQUIRE(aligned(A, 16) && aligned(B, 16) && lda % 4 == 0 && ldb % 4 == 0,
+                  "gemm f32: operands need 16-byte alignment and lda/ldb %% 4 == 0 (lda=%d ldb=%d)", lda, ldb);
+    int tm = ceil_div(M, FM), tn = ceil_div(N, FN);
+    int nt = ceil_div(K, FK);
+    if (split_k > nt) split_k = nt;
+    const float* a = (const float*)A;
+    const float* b = (const float*)B;
+    if (!trans_a && !trans_b) return launch_f32<false, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+    if (!trans_a && trans_b) return launch_f32<false, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+    if (trans_a && !trans_b) return launch_f32<true, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+    return launch_f32<true, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+}

@@ -1,0 +1,87 @@
+"""ctypes binding of libilvlm_hip.so (include/ilvlm_hip.h).  The product path has no CPU or
+PyTorch fallback: if the library is missing or a call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libilvlm_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_QUICKGELU_BWD, ACT_GELU_ERF_BWD = 0, 1, 2, 3, 4
+POOL_MAX, POOL_MEAN, POOL_SUM = 0, 1, 2
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias", vp), ("rowbias", vp), ("residual", vp), ("aux", vp), ("alpha_ptr", vp),
+                ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
+                ("out_group", i32), ("out_skip", i32)]
+
+
+class AdamWHyper(C.Structure):
+    _fields_ = [("lr", f32 * 16), ("weight_decay", f32 * 16), ("active", i32 * 16),
+                ("beta1", f32), ("beta2", f32), ("eps", f32), ("step", i32)]
+
+
+# name -> argtypes; every entry point declared in include/ilvlm_hip.h (tests check the .so exports them all)
+SIGNATURES = {
+    "ilvlm_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(GemmEpilogue), i32, vp],
+    "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
+    "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "ilvlm_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ilvlm_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ilvlm_embed_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ilvlm_embed_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ilvlm_patchify": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "ilvlm_cls_rows": [vp, vp, vp, i32, i32, i32, vp],
+    "ilvlm_batch_sum": [vp, vp, vp, i32, i32, i32, vp],
+    "ilvlm_gather_rows": [vp, vp, vp, i32, i32, i32, vp],
+    "ilvlm_scatter_rows": [vp, vp, vp, i32, i32, i32, vp],
+    "ilvlm_fdt_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp],
+    "ilvlm_fdt_pool_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],
+    "ilvlm_sparsemax_fwd": [vp, vp, i32, i32, vp],
+    "ilvlm_sparsemax_bwd": [vp, vp, vp, i32, i32, vp],
+    "ilvlm_softmax_fwd": [vp, vp, i32, i32, vp],
+    "ilvlm_softmax_bwd": [vp, vp, vp, i32, i32, vp],
+    "ilvlm_l2norm_fwd": [vp, vp, vp, i32, i32, f32, vp],
+    "ilvlm_l2norm_bwd": [vp, vp, vp, vp, i32, i32, f32, vp],
+    "ilvlm_logit_scale_fwd": [vp, vp, f32, vp],
+    "ilvlm_logit_scale_bwd": [vp, vp, vp, vp, i64, vp, vp, vp, vp],
+    "ilvlm_infonce_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp],
+    "ilvlm_topk_accuracy": [vp, i32, i32, i32, i32, vp, vp],
+    "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
+    "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
+    "ilvlm_scale": [vp, vp, f32, i64, vp],
+    "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
+    "ilvlm_selftest_fragments": [vp, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libilvlm_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C iterated-learning-for-vlm_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.ilvlm_version.restype = i32
+    lib.ilvlm_version.argtypes = []
+    lib.ilvlm_last_error.restype = C.c_char_p
+    lib.ilvlm_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("ilvlm %s failed (code %d): %s" % (what, rc, load().ilvlm_last_error().decode()))

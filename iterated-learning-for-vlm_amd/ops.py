@@ -1,0 +1,264 @@
+"""Thin tensor-level wrappers over the C ABI (include/ilvlm_hip.h).  PyTorch is used only for device
+memory and the current HIP stream; every computation below is a kernel of libilvlm_hip.so.  The
+wrappers check shapes/dtypes on the host (a kernel that indexes out of bounds can take the GPU
+down) and raise RuntimeError on any failure; there is no fallback path."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from .lib import F32, BF16, GemmEpilogue  # noqa: F401
+
+_TD = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    return _TD[t.dtype]
+
+
+def torch_dtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, name, dtype=None, shape=None):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a device tensor (no CPU fallback)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("%s: expected %s got %s" % (name, dtype, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError("%s: expected shape %s got %s" % (name, tuple(shape), tuple(t.shape)))
+
+
+def selftest_fragments():
+    out = torch.zeros(5, 64, 8, device="cuda", dtype=torch.float32)
+    L.check(L.load().ilvlm_selftest_fragments(out.data_ptr(), _stream()), "selftest")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, residual=None, aux=None, act=0,
+         alpha=1.0, alpha_ptr=None, accumulate=False, out_group=0, out_skip=0, split_k=1, M=None, N=None, K=None):
+    """out[m,n] = epilogue(sum_k A(m,k) B(n,k)); see ilvlm_gemm.  a, b: 2-D bf16 or fp32 (same dtype);
+    out: 2-D.  With out_group > 0, `out` is the token-stream tensor the rows are mapped into."""
+    if a.dtype != b.dtype:
+        raise RuntimeError("gemm: operand dtypes differ: %s %s" % (a.dtype, b.dtype))
+    _chk(a, "gemm.a"); _chk(b, "gemm.b"); _chk(out, "gemm.out")
+    m = (a.shape[1] if trans_a else a.shape[0]) if M is None else M
+    k = (a.shape[0] if trans_a else a.shape[1]) if K is None else K
+    n = (b.shape[1] if trans_b else b.shape[0]) if N is None else N
+    kb = b.shape[0] if trans_b else b.shape[1]
+    if kb != k and K is None:
+        raise RuntimeError("gemm: K mismatch %d vs %d" % (k, kb))
+    lda, ldb, ldc = a.stride(0), b.stride(0), out.stride(0)
+    rows_out = m if out_group <= 0 else (m // out_group) * (out_group + out_skip)
+    if out_group > 0 and m % out_group:
+        raise RuntimeError("gemm: M=%d not a multiple of out_group=%d" % (m, out_group))
+    if out.shape[0] < rows_out or out.shape[1] != n:
+        raise RuntimeError("gemm: out shape %s too small for [%d,%d]" % (tuple(out.shape), rows_out, n))
+    if bias is not None:
+        _chk(bias, "gemm.bias", torch.float32, (n,))
+    if rowbias is not None:
+        _chk(rowbias, "gemm.rowbias", torch.float32, (out_group + out_skip, n))
+    if residual is not None:
+        _chk(residual, "gemm.residual", torch.float32, out.shape)
+    if aux is not None:
+        _chk(aux, "gemm.aux", a.dtype, (m, n))
+        if aux.stride(0) != ldc:
+            raise RuntimeError("gemm: aux stride must equal out stride")
+    if accumulate and out.dtype != torch.float32:
+        raise RuntimeError("gemm: accumulate needs an fp32 output")
+    epi = GemmEpilogue(_p(bias), _p(rowbias), _p(residual), _p(aux), _p(alpha_ptr), float(alpha), int(act), dt(out),
+                       int(bool(accumulate)), int(out_group), int(out_skip))
+    L.check(L.load().ilvlm_gemm(dt(a), int(trans_a), int(trans_b), m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb,
+                                out.data_ptr(), ldc, C.byref(epi), int(split_k), _stream()), "gemm")
+    return out
+
+
+def wgrad_split(out_rows, out_cols, k, tile=128):
+    """split-K factor for a weight-gradient GEMM: enough workgroups to fill 256 CUs."""
+    tiles = math.ceil(out_rows / tile) * math.ceil(out_cols / tile)
+    s = max(1, min(16, round(512 / tiles)))
+    return max(1, min(s, k // 256 if k >= 256 else 1))
+
+
+# ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, group=0, skip=0):
+    L.check(L.load().ilvlm_layernorm_fwd(x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dt(y),
+                                         mean.data_ptr(), rstd.data_ptr(), rows, cols, eps, group, skip, _stream()),
+            "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, rows, cols, dres=None, dx_f32=None, dx_lp=None, act=0,
+                  act_aux=None, group=0, skip=0):
+    L.check(L.load().ilvlm_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), mean.data_ptr(), rstd.data_ptr(),
+                                         gamma.data_ptr(), _p(dres), _p(dx_f32), _p(dx_lp),
+                                         dt(dx_lp) if dx_lp is not None else 0, act, _p(act_aux), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), rows, cols, group, skip, _stream()), "layernorm_bwd")
+
+
+def attention_fwd(qkv, out, lse, B, Lq, H, causal):
+    _chk(qkv, "attn.qkv", None, (B * Lq, 3 * 64 * H)); _chk(out, "attn.out", qkv.dtype, (B * Lq, 64 * H))
+    _chk(lse, "attn.lse", torch.float32, (B, H, Lq))
+    L.check(L.load().ilvlm_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dt(qkv), B, Lq, H, int(causal),
+                                         _stream()), "attention_fwd")
+
+
+def attention_bwd(dout, qkv, out, lse, dqkv, B, Lq, H, causal):
+    _chk(dout, "attn.dout", qkv.dtype, (B * Lq, 64 * H)); _chk(dqkv, "attn.dqkv", qkv.dtype, (B * Lq, 3 * 64 * H))
+    L.check(L.load().ilvlm_attention_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                         dqkv.data_ptr(), dt(qkv), B, Lq, H, int(causal), _stream()), "attention_bwd")
+
+
+def embed_fwd(tokens, table, pos, x):
+    B, Lq = tokens.shape
+    _chk(tokens, "embed.tokens", torch.int64); _chk(x, "embed.x", torch.float32, (B * Lq, table.shape[1]))
+    _chk(pos, "embed.pos", torch.float32, (Lq, table.shape[1]))
+    L.check(L.load().ilvlm_embed_fwd(tokens.data_ptr(), table.data_ptr(), pos.data_ptr(), x.data_ptr(), B, Lq,
+                                     table.shape[1], table.shape[0], _stream()), "embed_fwd")
+
+
+def embed_bwd(tokens, dx, dtable, dpos):
+    B, Lq = tokens.shape
+    _chk(dx, "embed.dx", torch.float32, (B * Lq, dtable.shape[1]))
+    L.check(L.load().ilvlm_embed_bwd(tokens.data_ptr(), dx.data_ptr(), dtable.data_ptr(), _p(dpos), B, Lq,
+                                     dtable.shape[1], dtable.shape[0], _stream()), "embed_bwd")
+
+
+def patchify(images, patches, ps):
+    B, Cc, res, res2 = images.shape
+    g = res // ps
+    _chk(images, "patchify.images", torch.float32); _chk(patches, "patchify.out", None, (B * g * g, Cc * ps * ps))
+    if res != res2 or res % ps:
+        raise RuntimeError("patchify: bad image size")
+    L.check(L.load().ilvlm_patchify(images.data_ptr(), patches.data_ptr(), dt(patches), B, Cc, res, ps, _stream()),
+            "patchify")
+
+
+def cls_rows(cls, pos, tokens, B, Lq, W):
+    _chk(tokens, "cls_rows.tokens", torch.float32, (B * Lq, W))
+    L.check(L.load().ilvlm_cls_rows(cls.data_ptr(), pos.data_ptr(), tokens.data_ptr(), B, Lq, W, _stream()), "cls_rows")
+
+
+def batch_sum(x, out, out0, B, Lq, W):
+    _chk(x, "batch_sum.x", torch.float32, (B * Lq, W)); _chk(out, "batch_sum.out", torch.float32, (Lq, W))
+    L.check(L.load().ilvlm_batch_sum(x.data_ptr(), out.data_ptr(), _p(out0), B, Lq, W, _stream()), "batch_sum")
+
+
+def gather_rows(x, idx, y, B, Lq, W):
+    _chk(x, "gather.x", torch.float32, (B * Lq, W)); _chk(y, "gather.y", torch.float32, (B, W))
+    _chk(idx, "gather.idx", torch.int64, (B,))
+    L.check(L.load().ilvlm_gather_rows(x.data_ptr(), idx.data_ptr(), y.data_ptr(), B, Lq, W, _stream()), "gather_rows")
+
+
+def scatter_rows(dy, idx, dx, B, Lq, W):
+    _chk(dx, "scatter.dx", torch.float32, (B * Lq, W)); _chk(dy, "scatter.dy", torch.float32, (B, W))
+    L.check(L.load().ilvlm_scatter_rows(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, Lq, W, _stream()),
+            "scatter_rows")
+
+
+def fdt_pool_fwd(scores, mask, pooled, argmax, B, T, Cn, sqrt_d, temp, pool):
+    _chk(scores, "fdt.scores", torch.float32, (B * T, Cn)); _chk(pooled, "fdt.pooled", torch.float32, (B, Cn))
+    if mask is not None:
+        _chk(mask, "fdt.mask", torch.float32, (B, T))
+    if argmax is not None:
+        _chk(argmax, "fdt.argmax", torch.int32, (B, Cn))
+    L.check(L.load().ilvlm_fdt_pool_fwd(scores.data_ptr(), _p(mask), pooled.data_ptr(), _p(argmax), B, T, Cn, sqrt_d,
+                                        temp, pool, _stream()), "fdt_pool_fwd")
+
+
+def fdt_pool_bwd(dpooled, argmax, mask, dscores, B, T, Cn, sqrt_d, temp, pool):
+    _chk(dpooled, "fdt.dpooled", torch.float32, (B, Cn)); _chk(dscores, "fdt.dscores", None, (B * T, Cn))
+    L.check(L.load().ilvlm_fdt_pool_bwd(dpooled.data_ptr(), _p(argmax), _p(mask), dscores.data_ptr(), dt(dscores), B, T,
+                                        Cn, sqrt_d, temp, pool, _stream()), "fdt_pool_bwd")
+
+
+def _rows2(name, fn, *ts):
+    rows, cols = ts[0].shape
+    for t in ts:
+        _chk(t, name, torch.float32, (rows, cols))
+    L.check(fn(*[t.data_ptr() for t in ts], rows, cols, _stream()), name)
+
+
+def sparsemax_fwd(z, out):
+    _rows2("sparsemax_fwd", L.load().ilvlm_sparsemax_fwd, z, out)
+
+
+def sparsemax_bwd(out, g, dz):
+    _rows2("sparsemax_bwd", L.load().ilvlm_sparsemax_bwd, out, g, dz)
+
+
+def softmax_fwd(z, out):
+    _rows2("softmax_fwd", L.load().ilvlm_softmax_fwd, z, out)
+
+
+def softmax_bwd(out, g, dz):
+    _rows2("softmax_bwd", L.load().ilvlm_softmax_bwd, out, g, dz)
+
+
+def l2norm_fwd(x, y, norm, eps):
+    rows, cols = x.shape
+    _chk(x, "l2norm.x", torch.float32); _chk(y, "l2norm.y", torch.float32, x.shape); _chk(norm, "l2norm.norm", torch.float32, (rows,))
+    L.check(L.load().ilvlm_l2norm_fwd(x.data_ptr(), y.data_ptr(), norm.data_ptr(), rows, cols, eps, _stream()), "l2norm_fwd")
+
+
+def l2norm_bwd(x, norm, dy, dx, eps):
+    rows, cols = x.shape
+    _chk(dy, "l2norm.dy", torch.float32, x.shape); _chk(dx, "l2norm.dx", torch.float32, x.shape)
+    L.check(L.load().ilvlm_l2norm_bwd(x.data_ptr(), norm.data_ptr(), dy.data_ptr(), dx.data_ptr(), rows, cols, eps,
+                                      _stream()), "l2norm_bwd")
+
+
+def logit_scale_fwd(param, out, max_scale=100.0):
+    L.check(L.load().ilvlm_logit_scale_fwd(param.data_ptr(), out.data_ptr(), max_scale, _stream()), "logit_scale_fwd")
+
+
+def logit_scale_bwd(dli, li, dlt, lt, param, scale_used, dparam):
+    for t in (dli, li, dlt, lt):
+        _chk(t, "logit_scale_bwd", torch.float32, li.shape)
+    L.check(L.load().ilvlm_logit_scale_bwd(dli.data_ptr(), li.data_ptr(), dlt.data_ptr(), lt.data_ptr(), li.numel(),
+                                           param.data_ptr(), scale_used.data_ptr(), dparam.data_ptr(), _stream()),
+            "logit_scale_bwd")
+
+
+def infonce_fwd(li, lt, label_offset, loss, dli, dlt):
+    B, Bg = li.shape
+    for t in (li, lt, dli, dlt):
+        _chk(t, "infonce", torch.float32, (B, Bg))
+    L.check(L.load().ilvlm_infonce_fwd(li.data_ptr(), lt.data_ptr(), B, Bg, label_offset, loss.data_ptr(),
+                                       dli.data_ptr(), dlt.data_ptr(), _stream()), "infonce_fwd")
+
+
+def topk_accuracy(logits, label_offset, k, out):
+    B, Bg = logits.shape
+    _chk(logits, "topk.logits", torch.float32); _chk(out, "topk.out", torch.float32, (2,))
+    L.check(L.load().ilvlm_topk_accuracy(logits.data_ptr(), B, Bg, label_offset, k, out.data_ptr(), _stream()), "topk")
+
+
+def colsum(x, out):
+    rows, cols = x.shape
+    _chk(out, "colsum.out", torch.float32, (cols,))
+    if not x.is_cuda or x.stride(1) != 1:
+        raise RuntimeError("colsum: bad input")
+    L.check(L.load().ilvlm_colsum(x.data_ptr(), dt(x), out.data_ptr(), rows, cols, x.stride(0), _stream()), "colsum")
+
+
+def cast_f32(src, dst):
+    _chk(src, "cast.src", torch.float32); _chk(dst, "cast.dst")
+    if src.numel() != dst.numel():
+        raise RuntimeError("cast: size mismatch")
+    L.check(L.load().ilvlm_cast_f32(src.data_ptr(), dst.data_ptr(), dt(dst), src.numel(), _stream()), "cast_f32")
+
+
+def scale(x, y, a):
+    L.check(L.load().ilvlm_scale(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "scale")

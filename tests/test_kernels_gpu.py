@@ -1,0 +1,432 @@
+"""GPU parity tests of every C-ABI kernel against a plain PyTorch fp32 reference of the same op
+(computed on the CPU) and, where one exists, the oracle / golden fixture.  Run with `-m gpu`.
+Tolerances: fp32 kernels 1e-5..1e-4 relative (summation order), bf16 kernels 1e-2 (north_star)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import clip_oracle as O  # noqa: E402
+
+
+def _ops():
+    from ilvlm_amd import ops
+    return ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().double()
+    b = b.detach().float().cpu().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_fragment_maps():
+    """MFMA C/D map, operand K coverage and the ds_read_b64_tr_b16 lane map the kernels rely on."""
+    out = _ops().selftest_fragments().cpu()
+    lane = torch.arange(64)
+    g, c = lane // 16, lane % 16
+    assert torch.all(out[0, :, :4] == 496.0)
+    for j in range(8):
+        assert torch.equal(out[1, :, j], (8 * g + j).float()), "tr read k map, j=%d" % j
+        assert torch.equal(out[4, :, j], c.float()), "tr read col map, j=%d" % j
+    for r in range(4):
+        want = ((4 * g + r) * (c + 1)).float()
+        assert torch.equal(out[2, :, r], want), "bf16 mfma C/D map"
+        assert torch.equal(out[3, :, r], want), "f32 mfma C/D map"
+
+
+GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1000, 768, 512), (256, 256, 1032)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(dtype, ta, tb, M, N, K):
+    ops = _ops()
+    a = rnd(M, K, seed=1).to(dtype)
+    b = rnd(N, K, seed=2).to(dtype)
+    want = a.float() @ b.float().t()
+    A = dev(a.t() if ta else a)
+    B = dev(b.t() if tb else b)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+    ops.gemm(A, B, out, trans_a=bool(ta), trans_b=bool(tb))
+    assert rel(out, want) < 2e-5
+    if dtype == torch.bfloat16:
+        outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, B, outb, trans_a=bool(ta), trans_b=bool(tb))
+        assert rel(outb, want) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(dtype):
+    ops = _ops()
+    M, N, K = 392, 264, 136
+    a, b = rnd(M, K, seed=3).to(dtype), rnd(N, K, seed=4).to(dtype)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    base = a.float() @ b.float().t() / math.sqrt(K)
+    A, B = dev(a), dev(b)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    # bias + residual, fp32 out, alpha through both host and device scalars
+    out = torch.empty(M, N, device="cuda")
+    alpha_dev = torch.tensor([0.5], device="cuda")
+    ops.gemm(A, B, out, bias=dev(bias), residual=dev(res), alpha=2.0 / math.sqrt(K), alpha_ptr=alpha_dev)
+    assert rel(out, base + bias + res) < 2e-5
+    # activations forward: pre-activation saved to aux, output in compute dtype
+    for act, fn in ((1, O.quick_gelu), (2, O.gelu_erf)):
+        aux = torch.empty(M, N, device="cuda", dtype=dtype)
+        y = torch.empty(M, N, device="cuda", dtype=dtype)
+        ops.gemm(A, B, y, bias=dev(bias), aux=aux, act=act, alpha=1 / math.sqrt(K))
+        assert rel(aux, base + bias) < tol
+        assert rel(y, fn(base + bias)) < tol
+        # backward multiply by act'(aux)
+        u = (base + bias).to(dtype).float().requires_grad_(True)
+        fn(u).sum().backward()
+        dy = torch.empty(M, N, device="cuda", dtype=dtype)
+        ops.gemm(A, B, dy, aux=aux, act=act + 2, alpha=1 / math.sqrt(K))
+        assert rel(dy, base * u.grad) < (5e-5 if dtype == torch.float32 else 2e-2)
+    # row remap + rowbias (patch embedding epilogue): 8 images x 49 patches -> [8*50, N]
+    rb = rnd(50, N, seed=7)
+    tokens = torch.zeros(8 * 50, N, device="cuda")
+    ops.gemm(A, B, tokens, rowbias=dev(rb), out_group=49, out_skip=1)
+    want = torch.zeros(8, 50, N)
+    want[:, 1:, :] = (base * math.sqrt(K)).reshape(8, 49, N) + rb[1:]
+    assert rel(tokens, want.reshape(400, N)) < 2e-5
+    assert float(tokens.reshape(8, 50, N)[:, 0].abs().max()) == 0.0
+    # accumulate with split-K on top of existing contents (wgrad form: both operands K-strided)
+    for split in (1, 3):
+        acc = dev(res.clone())
+        ops.gemm(dev(a.t()), dev(b.t()), acc, trans_a=True, trans_b=True, accumulate=True, split_k=split)
+        assert rel(acc, res + base * math.sqrt(K)) < 2e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    ops = _ops()
+    a = torch.zeros(16, 12, device="cuda", dtype=torch.bfloat16)   # lda = 12 not a multiple of 8
+    out = torch.zeros(16, 16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, a, out)
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(16, 16), torch.zeros(16, 16), torch.zeros(16, 16))   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("cols", [768, 512, 128, 1024, 32])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_layernorm(cols, xdt, ydt):
+    ops = _ops()
+    rows = 101
+    x = (rnd(rows, cols, seed=1) * 3 + 0.5).to(xdt)
+    w, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = O.layer_norm(xr, wr, br)
+    dy = rnd(rows, cols, seed=4).to(ydt)
+    dres = rnd(rows, cols, seed=5)
+    y_ref.backward(dy.float())
+    X, W_, B_ = dev(x), dev(w), dev(b)
+    y = torch.empty(rows, cols, device="cuda", dtype=ydt)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(X, W_, B_, y, mean, rstd, rows, cols)
+    tol = 1e-5 if ydt == torch.float32 else 1e-2
+    assert rel(y, y_ref) < tol
+    dg, db = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    dx32 = torch.empty(rows, cols, device="cuda")
+    dxlp = torch.empty(rows, cols, device="cuda", dtype=ydt)
+    ops.layernorm_bwd(dev(dy), X, mean, rstd, W_, dg, db, rows, cols, dres=dev(dres), dx_f32=dx32, dx_lp=dxlp)
+    assert rel(dx32, xr.grad + dres) < 2e-5
+    assert rel(dxlp, xr.grad + dres) < tol
+    assert rel(dg, wr.grad) < 2e-5 and rel(db, br.grad) < 2e-5
+
+
+def test_layernorm_row_remap_and_act():
+    """Patch-token remap (group 49, skip 1) and the fused gelu' multiply of the q_map backward."""
+    ops = _ops()
+    Bn, P, Wd = 3, 49, 128
+    stream = rnd(Bn * (P + 1), Wd, seed=1)
+    w, b = 1 + 0.1 * rnd(Wd, seed=2), 0.1 * rnd(Wd, seed=3)
+    dense = stream.reshape(Bn, P + 1, Wd)[:, 1:].reshape(Bn * P, Wd).clone().requires_grad_(True)
+    y_ref = O.layer_norm(dense, w, b)
+    dy = rnd(Bn * P, Wd, seed=4)
+    y_ref.backward(dy)
+    y = torch.empty(Bn * P, Wd, device="cuda")
+    mean, rstd = torch.empty(Bn * P, device="cuda"), torch.empty(Bn * P, device="cuda")
+    ops.layernorm_fwd(dev(stream), dev(w), dev(b), y, mean, rstd, Bn * P, Wd, group=P, skip=1)
+    assert rel(y, y_ref) < 1e-5
+    dg, db = torch.zeros(Wd, device="cuda"), torch.zeros(Wd, device="cuda")
+    dstream = torch.zeros(Bn * (P + 1), Wd, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(stream), mean, rstd, dev(w), dg, db, Bn * P, Wd, dx_f32=dstream, group=P, skip=1)
+    got = dstream.reshape(Bn, P + 1, Wd)
+    assert float(got[:, 0].abs().max()) == 0.0
+    assert rel(got[:, 1:].reshape(Bn * P, Wd), dense.grad) < 2e-5
+    # act multiply on the low-precision copy
+    pre = rnd(Bn * P, Wd, seed=6).requires_grad_(True)
+    O.gelu_erf(pre).sum().backward()
+    dxlp = torch.empty(Bn * P, Wd, device="cuda")
+    dg.zero_(); db.zero_()
+    ops.layernorm_bwd(dev(dy), dev(dense.detach()), mean, rstd, dev(w), dg, db, Bn * P, Wd, dx_lp=dxlp, act=4,
+                      act_aux=dev(pre.detach()))
+    assert rel(dxlp, dense.grad * pre.grad) < 2e-5
+
+
+def attn_ref(qkv, B, L, H, causal):
+    E = 64 * H
+    q, k, v = qkv.reshape(B, L, 3 * E).split(E, dim=-1)
+    q = q.reshape(B, L, H, 64).transpose(1, 2) * 0.125
+    k = k.reshape(B, L, H, 64).transpose(1, 2)
+    v = v.reshape(B, L, H, 64).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + O.causal_mask(L)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * L, E), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, 0), (2, 77, 2, 1), (2, 5, 1, 0), (3, 24, 3, 1), (2, 64, 1, 1),
+                                          (2, 10, 1, 0), (1, 100, 2, 0), (1, 128, 1, 1)])
+def test_attention(dtype, B, L, H, causal):
+    ops = _ops()
+    if dtype == torch.float32 and L > 80:
+        pytest.skip("fp32 parity kernel supports L <= 80 in backward")
+    E = 64 * H
+    qkv = rnd(B * L, 3 * E, seed=1).to(dtype)
+    dout = rnd(B * L, E, seed=2).to(dtype)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = attn_ref(qr, B, L, H, causal)
+    o_ref.backward(dout.float())
+    Q = dev(qkv)
+    out = torch.full((B * L, E), float("nan"), device="cuda", dtype=dtype)
+    lse = torch.empty(B, H, L, device="cuda")
+    ops.attention_fwd(Q, out, lse, B, L, H, causal)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel(out, o_ref) < tol
+    assert rel(lse, lse_ref) < (1e-5 if dtype == torch.float32 else 5e-3)
+    dqkv = torch.full((B * L, 3 * E), float("nan"), device="cuda", dtype=dtype)
+    ops.attention_bwd(dev(dout), Q, out, lse, dqkv, B, L, H, causal)
+    assert rel(dqkv, qr.grad) < (5e-5 if dtype == torch.float32 else 2.5e-2)
+
+
+def test_embedding_and_tokens():
+    ops = _ops()
+    B, L, W, V = 5, 24, 64, 1000
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(0, V, (B, L), generator=g)
+    tok[0, :4] = 7          # repeated ids: scatter-add collisions
+    tok[1, :4] = 7
+    table, pos = rnd(V, W, seed=1), rnd(L, W, seed=2)
+    x = torch.empty(B * L, W, device="cuda")
+    ops.embed_fwd(dev(tok), dev(table), dev(pos), x)
+    assert rel(x, (table[tok] + pos).reshape(B * L, W)) == 0.0
+    dx = rnd(B * L, W, seed=3)
+    dtab, dpos = torch.zeros(V, W, device="cuda"), torch.zeros(L, W, device="cuda")
+    ops.embed_bwd(dev(tok), dev(dx), dtab, dpos)
+    want = torch.zeros(V, W).index_add_(0, tok.reshape(-1), dx)
+    assert rel(dtab, want) < 1e-6
+    assert rel(dpos, dx.reshape(B, L, W).sum(0)) < 1e-6
+    # patchify == unfold of conv2d(k=s=ps)
+    for ps, res in ((32, 64), (14, 42), (16, 48)):
+        img = rnd(3, 3, res, res, seed=4)
+        gdim = res // ps
+        for dtp in (torch.float32, torch.bfloat16):
+            out = torch.empty(3 * gdim * gdim, 3 * ps * ps, device="cuda", dtype=dtp)
+            ops.patchify(dev(img), out, ps)
+            want = torch.nn.functional.unfold(img, ps, stride=ps).transpose(1, 2).reshape(-1, 3 * ps * ps)
+            assert rel(out, want.to(dtp)) == 0.0
+    cls, p2 = rnd(W, seed=5), rnd(L, W, seed=6)
+    toks = torch.zeros(B * L, W, device="cuda")
+    ops.cls_rows(dev(cls), dev(p2), toks, B, L, W)
+    assert rel(toks.reshape(B, L, W)[:, 0], (cls + p2[0]).expand(B, W)) == 0.0
+    s_out, s0 = torch.zeros(L, W, device="cuda"), torch.zeros(W, device="cuda")
+    ops.batch_sum(dev(dx), s_out, s0, B, L, W)
+    assert rel(s_out, dx.reshape(B, L, W).sum(0)) < 1e-6 and rel(s0, dx.reshape(B, L, W)[:, 0].sum(0)) < 1e-6
+    idx = torch.tensor([3, 0, 23, 5, 9])
+    y = torch.empty(B, W, device="cuda")
+    ops.gather_rows(dev(dx), dev(idx), y, B, L, W)
+    assert rel(y, dx.reshape(B, L, W)[torch.arange(B), idx]) == 0.0
+    acc = torch.zeros(B * L, W, device="cuda")
+    ops.scatter_rows(y, dev(idx), acc, B, L, W)
+    want = torch.zeros(B, L, W)
+    want[torch.arange(B), idx] = dx.reshape(B, L, W)[torch.arange(B), idx]
+    assert rel(acc, want.reshape(B * L, W)) == 0.0
+
+
+@pytest.mark.parametrize("pool", ["max", "mean", "sum"])
+@pytest.mark.parametrize("temp", [1.0, 1000.0])
+def test_fdt_pool(pool, temp):
+    ops = _ops()
+    B, T, C, d = 4, 13, 320, 64
+    s = rnd(B * T, C, seed=1) * 5
+    mask = torch.zeros(B, T)
+    mask[1, 9:] = float("-inf")
+    mask[3, 3:] = float("-inf")
+    sr = s.clone().requires_grad_(True)
+    dot = sr.reshape(B, T, C) / math.sqrt(d)
+    dot = dot * ((mask == 0) * 1).unsqueeze(-1)
+    dot = dot / temp
+    pooled_ref = dot.max(1)[0] if pool == "max" else (dot.mean(1) if pool == "mean" else dot.sum(1))
+    gp = rnd(B, C, seed=2)
+    pooled_ref.backward(gp)
+    code = {"max": 0, "mean": 1, "sum": 2}[pool]
+    pooled = torch.empty(B, C, device="cuda")
+    am = torch.zeros(B, C, device="cuda", dtype=torch.int32)
+    ops.fdt_pool_fwd(dev(s), dev(mask), pooled, am, B, T, C, math.sqrt(d), temp, code)
+    assert rel(pooled, pooled_ref) < 1e-6
+    for dtp, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        ds = torch.empty(B * T, C, device="cuda", dtype=dtp)
+        ops.fdt_pool_bwd(dev(gp), am, dev(mask), ds, B, T, C, math.sqrt(d), temp, code)
+        assert rel(ds, sr.grad) < tol
+
+
+def test_sparsemax_softmax_golden(golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "g3_ops.npz"))
+    z, go = torch.from_numpy(g["sparsemax.z"]), torch.from_numpy(g["sparsemax.g"])
+    out = torch.empty_like(z, device="cuda")
+    ops.sparsemax_fwd(dev(z), out)
+    assert rel(out, torch.from_numpy(g["sparsemax.out"])) < 1e-5      # reference Sparsemax output
+    assert abs(float(out.sum(-1).sub(1).abs().max())) < 1e-4
+    dz = torch.empty_like(out)
+    ops.sparsemax_bwd(out, dev(go), dz)
+    assert rel(dz, torch.from_numpy(g["sparsemax.dz"])) < 5e-5       # reference autograd through sort/cumsum
+    # random rows at odd widths + softmax
+    for cols in (128, 320, 4096, 5000):
+        zz = rnd(6, cols, seed=cols) * 3
+        zr = zz.clone().requires_grad_(True)
+        gg = rnd(6, cols, seed=cols + 1)
+        O.sparsemax(zr).backward(gg)
+        o2 = torch.empty(6, cols, device="cuda")
+        ops.sparsemax_fwd(dev(zz), o2)
+        assert rel(o2, O.sparsemax(zz)) < 1e-5
+        d2 = torch.empty_like(o2)
+        ops.sparsemax_bwd(o2, dev(gg), d2)
+        assert rel(d2, zr.grad) < 5e-5
+        zr2 = zz.clone().requires_grad_(True)
+        torch.softmax(zr2, -1).backward(gg)
+        ops.softmax_fwd(dev(zz), o2)
+        assert rel(o2, torch.softmax(zz, -1)) < 1e-5
+        ops.softmax_bwd(o2, dev(gg), d2)
+        assert rel(d2, zr2.grad) < 5e-5
+
+
+def test_l2norm_scale_infonce_topk(golden_dir):
+    ops = _ops()
+    x = rnd(9, 96, seed=1)
+    x[4] = 0          # zero row: x / (0 + eps) = 0, gradient dy / eps
+    for eps in (1e-10, 0.0):
+        xx = x.clone()
+        if eps == 0.0:
+            xx[4] = 1.0
+        xr = xx.clone().requires_grad_(True)
+        y_ref = xr / (xr.norm(dim=-1, keepdim=True) + eps)
+        dy = rnd(9, 96, seed=2)
+        y_ref.backward(dy)
+        y, n = torch.empty(9, 96, device="cuda"), torch.empty(9, device="cuda")
+        ops.l2norm_fwd(dev(xx), y, n, eps)
+        assert rel(y, y_ref) < 1e-6
+        dx = torch.empty_like(y)
+        ops.l2norm_bwd(dev(xx), n, dev(dy), dx, eps)
+        keep = torch.ones(9, dtype=torch.bool)
+        if eps > 0:
+            keep[4] = False     # reference gives dy/eps (1e10 scale) there; checked separately
+            assert rel(dx[4], dy[4] / eps) < 1e-5
+        assert rel(dx[keep.cuda()], xr.grad[keep]) < 1e-5
+    # temperature and its gradient, including the clamp regime exp(5) > 100
+    for ls in (math.log(1 / 0.07), 5.0):
+        p = torch.tensor([ls], requires_grad=True)
+        cos_i, cos_t = rnd(6, 12, seed=3), rnd(6, 12, seed=4)
+        scale = torch.clamp(p.exp().detach(), max=100) + (p.exp() - p.exp().detach())
+        li, lt = cos_i * scale, cos_t * scale
+        gi, gt = rnd(6, 12, seed=5), rnd(6, 12, seed=6)
+        (li * gi + lt * gt).sum().backward()
+        sc = torch.empty(1, device="cuda")
+        ops.logit_scale_fwd(dev(p.detach()), sc)
+        assert rel(sc, scale.detach()) < 1e-6
+        dp = torch.zeros(1, device="cuda")
+        ops.logit_scale_bwd(dev(gi), dev(li.detach()), dev(gt), dev(lt.detach()), dev(p.detach()), sc, dp)
+        assert rel(dp, p.grad) < 1e-5
+    g = np.load(os.path.join(golden_dir, "g3_ops.npz"))
+    li, lt = torch.from_numpy(g["ce.li"]), torch.from_numpy(g["ce.lt"])
+    loss = torch.empty(1, device="cuda")
+    dli, dlt = torch.empty(4, 16, device="cuda"), torch.empty(4, 16, device="cuda")
+    ops.infonce_fwd(dev(li), dev(lt), 8, loss, dli, dlt)          # rank 2 of 4, local batch 4
+    assert abs(float(loss) - float(g["ce.loss"])) < 1e-5 * abs(float(g["ce.loss"]))
+    assert rel(dli, torch.from_numpy(g["ce.dli"])) < 1e-5 and rel(dlt, torch.from_numpy(g["ce.dlt"])) < 1e-5
+    lg = rnd(32, 96, seed=7)
+    labels = 32 + torch.arange(32)
+    want = O.accuracy(lg, labels, topk=(1, 5))
+    acc = torch.empty(2, device="cuda")
+    ops.topk_accuracy(dev(lg), 32, 5, acc)
+    assert abs(float(acc[0]) - float(want[0])) < 1e-4 and abs(float(acc[1]) - float(want[1])) < 1e-4
+
+
+def test_colsum_cast_scale():
+    ops = _ops()
+    for dtp in (torch.float32, torch.bfloat16):
+        x = rnd(1000, 264, seed=1).to(dtp)
+        out = torch.ones(264, device="cuda")
+        ops.colsum(dev(x), out)
+        assert rel(out, 1 + x.float().sum(0)) < 1e-5
+    src = rnd(100003, seed=2)
+    for n in (100003, 4096, 5):
+        s = dev(src[:n].clone())
+        d = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+        ops.cast_f32(s, d)
+        assert torch.equal(d.cpu(), src[:n].to(torch.bfloat16))
+    y = torch.empty(100003, device="cuda")
+    ops.scale(dev(src), y, 0.25)
+    assert rel(y, src * 0.25) == 0.0
+
+
+def test_adamw_matches_torch():
+    import ctypes as C
+    from ilvlm_amd import lib as L
+    sizes = [5000, 17, 4096, 70000]
+    groups = [0, 1, 2, 1]           # group 2 inactive
+    lrs, wds = [1e-3, 2e-3, 5e-1], [0.1, 0.0, 0.3]
+    n = sum(sizes)
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2)
+    P, G = dev(p0), dev(g0)
+    M, V = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    offs, cnts, grps = [], [], []
+    o = 0
+    for sz, gr in zip(sizes, groups):
+        for c in range(0, sz, 4096):
+            offs.append(o + c); cnts.append(min(4096, sz - c)); grps.append(gr)
+        o += sz
+    co = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    cc = torch.tensor(cnts, dtype=torch.int32, device="cuda")
+    cg = torch.tensor(grps, dtype=torch.int32, device="cuda")
+    pr, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        h = L.AdamWHyper()
+        for i in range(3):
+            h.lr[i], h.weight_decay[i], h.active[i] = lrs[i], wds[i], int(i != 2)
+        h.beta1, h.beta2, h.eps, h.step = 0.9, 0.98, 1e-8, step
+        L.check(L.load().ilvlm_adamw_step(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), shadow.data_ptr(),
+                                          co.data_ptr(), cc.data_ptr(), cg.data_ptr(), len(offs), C.byref(h),
+                                          torch.cuda.current_stream().cuda_stream), "adamw")
+        o = 0
+        for sz, gr in zip(sizes, groups):
+            if gr != 2:
+                sl = slice(o, o + sz)
+                O.adamw_step(pr[sl], g0[sl], m[sl], v[sl], step, lrs[gr], 0.9, 0.98, 1e-8, wds[gr])
+            o += sz
+    assert rel(P, pr) < 1e-6 and rel(M, m) < 1e-6 and rel(V, v) < 1e-6
+    act = torch.ones(n, dtype=torch.bool)
+    act[sizes[0] + sizes[1]: sizes[0] + sizes[1] + sizes[2]] = False
+    assert torch.equal(shadow.cpu()[act], pr.to(torch.bfloat16)[act])
+    assert torch.equal(P.cpu()[~act], p0[~act])
