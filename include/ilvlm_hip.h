@@ -58,7 +58,8 @@ const char* ilvlm_last_error(void);
  * out_group > 0 maps output row m to (m / out_group) * (out_group + out_skip) + out_skip + m % out_group
  *   (patch tokens written behind the class token, visual_transformer.py:56-63).
  * split_k >= 1 partitions K over that many workgroups per tile (requires accumulate = 1 if > 1).
- * Alignment: bf16 operands need 16-byte aligned bases and lda/ldb multiples of 8; fp32 multiples of 4.
+ * Alignment: bf16 operands need 16-byte aligned bases and lda/ldb multiples of 8; fp32 operands may have any
+ *   leading dimension (float4 staging when 16-byte aligned rows, scalar loads otherwise).
  */
 typedef struct ilvlm_gemm_epilogue {
     const float* bias;      /* [N] or NULL */

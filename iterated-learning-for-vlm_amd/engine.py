@@ -1,0 +1,468 @@
+"""Host-side execution engine of the CLIP / CLIP+FDT step on MI355X.
+
+The engine owns
+  * a flat fp32 PARAMETER ARENA (the nn.Module parameters are views into it, reference names and
+    shapes untouched), a flat GRADIENT ARENA (every .grad is a view into it; weight gradients are
+    accumulated there directly by the kernels), and a bf16 SHADOW of the parameters that the MFMA
+    GEMMs read (refreshed by one cast kernel per forward);
+  * the forward / backward composition of the hot path as explicit kernel sequences (no autograd graph
+    inside: activations needed by the backward pass are kept in plain lists), one C-ABI call per kernel.
+PyTorch supplies device memory, streams and torch.distributed only.
+
+Reference semantics restated here (file:line relative to the reference root):
+  VisualTransformer.forward        prototype/model/image_encoder/visual_transformer.py:55-91
+  ResidualAttentionBlock.forward   prototype/model/image_encoder/base_transformer.py:50-62 (text twin :50-59)
+  TextTransformer.forward          prototype/model/text_encoder/text_transformer.py:211-338
+  Query_model.forward              prototype/model/clip_fdt.py:96-161
+  Clip_FDT.forward                 prototype/model/clip_fdt.py:390-428
+  CLIP.forward                     prototype/model/clip.py:125-149
+"""
+import math
+
+import torch
+
+from . import ops
+from .lib import (F32, BF16, ACT_QUICKGELU, ACT_GELU_ERF, ACT_QUICKGELU_BWD, ACT_GELU_ERF_BWD, POOL_MAX, POOL_MEAN,
+                  POOL_SUM)
+
+ALIGN = 64   # elements; keeps every parameter view 256-byte aligned
+POOLS = {"max": POOL_MAX, "mean": POOL_MEAN, "sum": POOL_SUM}
+
+
+class ParamArena:
+    """Flat fp32 parameter / gradient storage with an optional bf16 shadow."""
+
+    def __init__(self, module, precision):
+        self.named = [(n, p) for n, p in module.named_parameters()]
+        dev = self.named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("ilvlm: the model must be on the GPU (model.cuda()) before its first forward; "
+                               "there is no CPU execution path")
+        self.offsets, off = {}, 0
+        for n, p in self.named:
+            self.offsets[n] = off
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.P = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.G = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.S = torch.zeros(off, device=dev, dtype=torch.bfloat16) if precision == "bf16" else None
+        self.views, self.gviews, self.sviews = {}, {}, {}
+        for n, p in self.named:
+            o, k = self.offsets[n], p.numel()
+            v = self.P[o:o + k].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.views[n] = v
+            self.gviews[n] = self.G[o:o + k].view(p.shape)
+            p.grad = self.gviews[n]
+            if self.S is not None:
+                self.sviews[n] = self.S[o:o + k].view(p.shape)
+
+    def sync_in(self):
+        """Re-adopt parameters whose storage was replaced behind our back (p.data = ..., load_state_dict on a
+        moved module) and re-attach gradient views dropped by zero_grad(set_to_none=True)."""
+        for n, p in self.named:
+            v = self.views[n]
+            if p.data_ptr() != v.data_ptr():
+                v.copy_(p.data.to(v.device, torch.float32))
+                p.data = v
+            if p.grad is None or p.grad.data_ptr() != self.gviews[n].data_ptr():
+                if p.grad is not None:
+                    self.gviews[n].copy_(p.grad)
+                p.grad = self.gviews[n]
+
+    def refresh_shadow(self):
+        if self.S is not None:
+            ops.cast_f32(self.P, self.S)
+
+    def zero_grad(self):
+        self.G.zero_()
+
+    def range_of(self, prefix):
+        """[begin, end) element range of the parameters whose name starts with prefix (contiguous by construction)."""
+        names = [n for n, _ in self.named if n.startswith(prefix)]
+        if not names:
+            return (0, 0)
+        last = names[-1]
+        p = dict(self.named)[last]
+        return self.offsets[names[0]], self.offsets[last] + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+class Engine:
+    """Executes the towers of one model instance.  `cfg` keys: precision ('bf16'|'fp32'), v_heads, t_heads,
+    patch, res, ctx, fdt (bool) and for FDT: att_func, pool."""
+
+    def __init__(self, module, cfg):
+        self.m = module
+        self.cfg = cfg
+        self.precision = cfg["precision"]
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (self.precision,))
+        self.T = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        self.arena = None
+
+    # ------------------------------------------------------------------ parameters
+    def prepare(self):
+        if self.arena is None:
+            self.arena = ParamArena(self.m, self.precision)
+        else:
+            self.arena.sync_in()
+        self.arena.refresh_shadow()
+        a = self.arena
+        self.Wf = a.views                                     # fp32 masters
+        self.Wc = a.sviews if self.precision == "bf16" else a.views   # GEMM operands
+        self.Gr = a.gviews
+        self.req = {n: p.requires_grad for n, p in a.named}
+
+    def _mat(self, name):
+        w = self.Wc[name]
+        return w if w.dim() == 2 else w.reshape(w.shape[0], -1)
+
+    # ------------------------------------------------------------------ helpers
+    def _linear_bwd(self, dy, x, wname, bname, need_dx=True, dx_act=0, dx_aux=None):
+        """dy: [M,N] T; x: [M,K] T.  Accumulates dW (and db) into the gradient arena, returns dx (T) or None."""
+        M, N = dy.shape
+        K = x.shape[1]
+        if self.req[wname]:
+            ops.gemm(dy, x, self.Gr[wname].reshape(N, -1), trans_a=True, trans_b=True, accumulate=True,
+                     split_k=ops.wgrad_split(N, K, M, 128 if self.T == torch.bfloat16 else 64))
+        if bname is not None and self.req[bname]:
+            ops.colsum(dy, self.Gr[bname])
+        if not need_dx:
+            return None
+        dx = _empty((M, K), self.T, dy)
+        ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act)
+        return dx
+
+    # ------------------------------------------------------------------ transformer block
+    def block_fwd(self, x_in, pre, B, L, H, causal, save):
+        M, E = x_in.shape
+        T = self.T
+        Wf = self.Wf
+        h1 = _empty((M, E), T, x_in); mean1 = _empty((M,), torch.float32, x_in); rstd1 = torch.empty_like(mean1)
+        ops.layernorm_fwd(x_in, Wf[pre + "ln_1.weight"], Wf[pre + "ln_1.bias"], h1, mean1, rstd1, M, E)
+        qkv = _empty((M, 3 * E), T, x_in)
+        ops.gemm(h1, self._mat(pre + "attn.in_proj_weight"), qkv, bias=Wf[pre + "attn.in_proj_bias"])
+        att = _empty((M, E), T, x_in); lse = _empty((B, H, L), torch.float32, x_in)
+        ops.attention_fwd(qkv, att, lse, B, L, H, causal)
+        x_mid = _empty((M, E), torch.float32, x_in)
+        ops.gemm(att, self._mat(pre + "attn.out_proj.weight"), x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
+        h2 = _empty((M, E), T, x_in); mean2 = torch.empty_like(mean1); rstd2 = torch.empty_like(mean1)
+        ops.layernorm_fwd(x_mid, Wf[pre + "ln_2.weight"], Wf[pre + "ln_2.bias"], h2, mean2, rstd2, M, E)
+        u = _empty((M, 4 * E), T, x_in); g = _empty((M, 4 * E), T, x_in)
+        ops.gemm(h2, self._mat(pre + "mlp.c_fc.weight"), g, bias=Wf[pre + "mlp.c_fc.bias"], aux=u, act=ACT_QUICKGELU)
+        x_out = _empty((M, E), torch.float32, x_in)
+        ops.gemm(g, self._mat(pre + "mlp.c_proj.weight"), x_out, bias=Wf[pre + "mlp.c_proj.bias"], residual=x_mid)
+        saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g) if save else None
+        return x_out, saved
+
+    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal):
+        """dx_f32: fp32 gradient of the block output; dx_lp: the same in T (None in fp32 mode).  Returns the pair
+        for the block input."""
+        x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
+        M, E = x_in.shape
+        T, Wf, Gr = self.T, self.Wf, self.Gr
+        lp = T != torch.float32
+        dy = dx_lp if lp else dx_f32
+        # MLP: x_out = x_mid + c_proj(quickgelu(c_fc(h2)))
+        du = self._linear_bwd(dy, g, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dx_act=ACT_QUICKGELU_BWD, dx_aux=u)
+        dh2 = self._linear_bwd(du, h2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias")
+        dmid = _empty((M, E), torch.float32, x_in)
+        dmid_lp = _empty((M, E), T, x_in) if lp else None
+        ops.layernorm_bwd(dh2, x_mid, mean2, rstd2, Wf[pre + "ln_2.weight"], Gr[pre + "ln_2.weight"], Gr[pre + "ln_2.bias"],
+                          M, E, dres=dx_f32, dx_f32=dmid, dx_lp=dmid_lp)
+        dy = dmid_lp if lp else dmid
+        # attention: x_mid = x_in + out_proj(attn(in_proj(h1)))
+        da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias")
+        dqkv = _empty((M, 3 * E), T, x_in)
+        ops.attention_bwd(da, qkv, att, lse, dqkv, B, L, H, causal)
+        dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias")
+        din = _empty((M, E), torch.float32, x_in)
+        din_lp = _empty((M, E), T, x_in) if lp else None
+        ops.layernorm_bwd(dh1, x_in, mean1, rstd1, Wf[pre + "ln_1.weight"], Gr[pre + "ln_1.weight"], Gr[pre + "ln_1.bias"],
+                          M, E, dres=dmid, dx_f32=din, dx_lp=din_lp)
+        return din, din_lp
+
+    # ------------------------------------------------------------------ vision tower
+    def vision_fwd(self, images, save):
+        cfg, Wf, T = self.cfg, self.Wf, self.T
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != cfg["res"] or images.shape[3] != cfg["res"]:
+            raise RuntimeError("images must be [B,3,%d,%d], got %s" % (cfg["res"], cfg["res"], tuple(images.shape)))
+        images = images.contiguous().float()
+        B, ps = images.shape[0], cfg["patch"]
+        g = cfg["res"] // ps
+        P, Lv = g * g, g * g + 1
+        W = Wf["visual.class_embedding"].shape[0]
+        patches = _empty((B * P, 3 * ps * ps), T, images)
+        ops.patchify(images, patches, ps)
+        tokens = _empty((B * Lv, W), torch.float32, images)
+        pos = Wf["visual.positional_embedding"]
+        ops.cls_rows(Wf["visual.class_embedding"], pos, tokens, B, Lv, W)
+        ops.gemm(patches, self._mat("visual.conv1.weight"), tokens, rowbias=pos, out_group=P, out_skip=1)
+        x = _empty((B * Lv, W), torch.float32, images)
+        mean0 = _empty((B * Lv,), torch.float32, images); rstd0 = torch.empty_like(mean0)
+        ops.layernorm_fwd(tokens, Wf["visual.ln_pre.weight"], Wf["visual.ln_pre.bias"], x, mean0, rstd0, B * Lv, W)
+        blocks = []
+        for i in range(cfg["v_layers"]):
+            x, s = self.block_fwd(x, "visual.transformer.resblocks.%d." % i, B, Lv, cfg["v_heads"], 0, save)
+            blocks.append(s)
+        saved = dict(B=B, P=P, Lv=Lv, W=W, patches=patches if self.req["visual.conv1.weight"] else None, tokens=tokens,
+                     mean0=mean0, rstd0=rstd0, blocks=blocks) if save else None
+        return x, saved     # x: final residual stream [B*Lv, W] fp32 (dense patch tokens are rows 1.. of each image)
+
+    def vision_bwd(self, saved, dx_f32, dx_lp):
+        cfg, Wf, Gr = self.cfg, self.Wf, self.Gr
+        B, Lv, W = saved["B"], saved["Lv"], saved["W"]
+        for i in reversed(range(cfg["v_layers"])):
+            dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "visual.transformer.resblocks.%d." % i, dx_f32, dx_lp, B, Lv,
+                                           cfg["v_heads"], 0)
+        dtok = _empty((B * Lv, W), torch.float32, dx_f32)
+        ops.layernorm_bwd(dx_f32, saved["tokens"], saved["mean0"], saved["rstd0"], Wf["visual.ln_pre.weight"],
+                          Gr["visual.ln_pre.weight"], Gr["visual.ln_pre.bias"], B * Lv, W, dx_f32=dtok)
+        need_pos, need_cls = self.req["visual.positional_embedding"], self.req["visual.class_embedding"]
+        if need_pos or need_cls:
+            scratch = Gr["visual.positional_embedding"] if need_pos else torch.zeros_like(Gr["visual.positional_embedding"])
+            ops.batch_sum(dtok, scratch, Gr["visual.class_embedding"] if need_cls else None, B, Lv, W)
+        if self.req["visual.conv1.weight"]:     # frozen by train() in the reference; honoured if someone unfreezes it
+            dpatch = dtok.view(B, Lv, W)[:, 1:, :].reshape(B * saved["P"], W).to(self.T).contiguous()
+            self._linear_bwd(dpatch, saved["patches"], "visual.conv1.weight", None, need_dx=False)
+
+    def vision_pooled(self, x_final, B, Lv, save):
+        """ln_post(cls) @ proj -> (projected [B,D] fp32, saved).  Used by the baseline CLIP loss and encode_image."""
+        Wf = self.Wf
+        W = x_final.shape[1]
+        idx = torch.zeros(B, dtype=torch.int64, device=x_final.device)
+        cls = _empty((B, W), torch.float32, x_final)
+        ops.gather_rows(x_final, idx, cls, B, Lv, W)
+        feat = torch.empty_like(cls); mean = _empty((B,), torch.float32, cls); rstd = torch.empty_like(mean)
+        ops.layernorm_fwd(cls, Wf["visual.ln_post.weight"], Wf["visual.ln_post.bias"], feat, mean, rstd, B, W)
+        proj = Wf["visual.proj"]                     # [W, D] stored K-major -> trans_b
+        out = _empty((B, proj.shape[1]), torch.float32, cls)
+        ops.gemm(feat, proj, out, trans_b=True)
+        return out, feat, ((idx, cls, feat, mean, rstd) if save else None)
+
+    def vision_pooled_bwd(self, saved, dout, dx_stream, B, Lv):
+        """Adds the pooled-path gradient into the fp32 stream gradient dx_stream [B*Lv, W]."""
+        idx, cls, feat, mean, rstd = saved
+        Wf, Gr = self.Wf, self.Gr
+        W = cls.shape[1]
+        if self.req["visual.proj"]:
+            ops.gemm(feat, dout, Gr["visual.proj"], trans_a=True, trans_b=True, accumulate=True)   # [W,D] += feat^T dout
+        dfeat = torch.empty_like(feat)
+        ops.gemm(dout, Wf["visual.proj"], dfeat)      # dout [B,D] . proj[W,D]^T
+        dcls = torch.empty_like(cls)
+        ops.layernorm_bwd(dfeat, cls, mean, rstd, Wf["visual.ln_post.weight"], Gr["visual.ln_post.weight"],
+                          Gr["visual.ln_post.bias"], B, W, dx_f32=dcls)
+        ops.scatter_rows(dcls, idx, dx_stream, B, Lv, W)
+
+    # ------------------------------------------------------------------ text tower
+    def text_fwd(self, tokens, save):
+        cfg, Wf = self.cfg, self.Wf
+        if tokens.dim() != 2 or tokens.shape[1] != cfg["ctx"] or tokens.dtype != torch.int64:
+            raise RuntimeError("tokens must be int64 [B,%d], got %s %s" % (cfg["ctx"], tuple(tokens.shape), tokens.dtype))
+        tokens = tokens.contiguous()
+        B, Lt = tokens.shape
+        table = Wf["encode_text.token_embedding.weight"]
+        Wt = table.shape[1]
+        x = _empty((B * Lt, Wt), torch.float32, table)
+        ops.embed_fwd(tokens, table, Wf["encode_text.positional_embedding"], x)
+        blocks = []
+        for i in range(cfg["t_layers"]):
+            x, s = self.block_fwd(x, "encode_text.transformer.resblocks.%d." % i, B, Lt, cfg["t_heads"], 1, save)
+            blocks.append(s)
+        saved = dict(B=B, Lt=Lt, Wt=Wt, tokens=tokens, blocks=blocks) if save else None
+        return x, saved       # final residual stream BEFORE ln_final
+
+    def text_bwd(self, saved, dx_f32, dx_lp):
+        cfg, Gr = self.cfg, self.Gr
+        B, Lt = saved["B"], saved["Lt"]
+        for i in reversed(range(cfg["t_layers"])):
+            dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
+                                           Lt, cfg["t_heads"], 1)
+        need_tab, need_pos = self.req["encode_text.token_embedding.weight"], self.req["encode_text.positional_embedding"]
+        if need_tab:
+            ops.embed_bwd(saved["tokens"], dx_f32, Gr["encode_text.token_embedding.weight"],
+                          Gr["encode_text.positional_embedding"] if need_pos else None)
+        elif need_pos:
+            ops.batch_sum(dx_f32, Gr["encode_text.positional_embedding"], None, B, Lt, saved["Wt"])
+
+    def text_words(self, x_final, save):
+        """ln_final over every token -> word features [B*Lt, Wt] in T."""
+        Wf = self.Wf
+        M, Wt = x_final.shape
+        words = _empty((M, Wt), self.T, x_final); mean = _empty((M,), torch.float32, x_final); rstd = torch.empty_like(mean)
+        ops.layernorm_fwd(x_final, Wf["encode_text.ln_final.weight"], Wf["encode_text.ln_final.bias"], words, mean, rstd, M, Wt)
+        return words, ((x_final, mean, rstd) if save else None)
+
+    def text_words_bwd(self, saved, dwords_f32):
+        x_final, mean, rstd = saved
+        M, Wt = x_final.shape
+        lp = self.T != torch.float32
+        dx = torch.empty_like(x_final)
+        dx_lp = _empty((M, Wt), self.T, x_final) if lp else None
+        ops.layernorm_bwd(dwords_f32, x_final, mean, rstd, self.Wf["encode_text.ln_final.weight"],
+                          self.Gr["encode_text.ln_final.weight"], self.Gr["encode_text.ln_final.bias"], M, Wt, dx_f32=dx,
+                          dx_lp=dx_lp)
+        return dx, dx_lp
+
+    def text_pooled(self, x_final, tokens, B, Lt, save):
+        """ln_final at the EOT position (argmax of the ids, text_transformer.py:248) then text_projection."""
+        Wf = self.Wf
+        Wt = x_final.shape[1]
+        idx = tokens.argmax(dim=-1)
+        row = _empty((B, Wt), torch.float32, x_final)
+        ops.gather_rows(x_final, idx, row, B, Lt, Wt)
+        feat = torch.empty_like(row); mean = _empty((B,), torch.float32, row); rstd = torch.empty_like(mean)
+        ops.layernorm_fwd(row, Wf["encode_text.ln_final.weight"], Wf["encode_text.ln_final.bias"], feat, mean, rstd, B, Wt)
+        w = Wf["encode_text.text_projection.weight"]
+        out = _empty((B, w.shape[0]), torch.float32, row)
+        ops.gemm(feat, w, out, bias=Wf["encode_text.text_projection.bias"])
+        return out, feat, ((idx, row, feat, mean, rstd) if save else None)
+
+    def text_pooled_bwd(self, saved, dout, dx_stream, B, Lt):
+        idx, row, feat, mean, rstd = saved
+        Wf, Gr = self.Wf, self.Gr
+        Wt = row.shape[1]
+        w = Wf["encode_text.text_projection.weight"]
+        if self.req["encode_text.text_projection.weight"]:
+            ops.gemm(dout, feat, Gr["encode_text.text_projection.weight"], trans_a=True, trans_b=True, accumulate=True)
+        if self.req["encode_text.text_projection.bias"]:
+            ops.colsum(dout, Gr["encode_text.text_projection.bias"])
+        dfeat = torch.empty_like(feat)
+        ops.gemm(dout, w, dfeat, trans_b=True)
+        drow = torch.empty_like(row)
+        ops.layernorm_bwd(dfeat, row, mean, rstd, Wf["encode_text.ln_final.weight"], Gr["encode_text.ln_final.weight"],
+                          Gr["encode_text.ln_final.bias"], B, Wt, dx_f32=drow)
+        ops.scatter_rows(drow, idx, dx_stream, B, Lt, Wt)
+
+    # ------------------------------------------------------------------ FDT query model
+    def qmap_fwd(self, ft, side, rows, ftdim, group, skip, save):
+        """q_map: LN -> Linear -> erf-GELU -> LN -> Linear.  ft is the fp32 token stream (image, remapped rows) or the
+        T word features (text).  Returns q [rows, d] in T."""
+        Wf, T = self.Wf, self.T
+        pre = side + "q_map."
+        d = Wf[pre + "1.weight"].shape[0]
+        a0 = _empty((rows, ftdim), T, ft); m0 = _empty((rows,), torch.float32, ft); r0 = torch.empty_like(m0)
+        ops.layernorm_fwd(ft, Wf[pre + "0.weight"], Wf[pre + "0.bias"], a0, m0, r0, rows, ftdim, group=group, skip=skip)
+        pre1 = _empty((rows, d), T, ft); h1 = _empty((rows, d), T, ft)
+        ops.gemm(a0, self._mat(pre + "1.weight"), h1, bias=Wf[pre + "1.bias"], aux=pre1, act=ACT_GELU_ERF)
+        a3 = _empty((rows, d), T, ft); m3 = torch.empty_like(m0); r3 = torch.empty_like(m0)
+        ops.layernorm_fwd(h1, Wf[pre + "3.weight"], Wf[pre + "3.bias"], a3, m3, r3, rows, d)
+        q = _empty((rows, d), T, ft)
+        ops.gemm(a3, self._mat(pre + "4.weight"), q, bias=Wf[pre + "4.bias"])
+        return q, ((ft, a0, m0, r0, pre1, h1, a3, m3, r3, q, group, skip) if save else None)
+
+    def qmap_bwd(self, saved, side, dq, dstream_f32=None, dstream_lp=None):
+        """dq [rows,d] T.  Image side: writes the token-stream gradient into dstream_* (remapped rows, pre-zeroed).
+        Text side: returns d(word features) fp32."""
+        ft, a0, m0, r0, pre1, h1, a3, m3, r3, q, group, skip = saved
+        Wf, Gr, T = self.Wf, self.Gr, self.T
+        pre = side + "q_map."
+        rows, d = dq.shape
+        ftdim = a0.shape[1]
+        da3 = self._linear_bwd(dq, a3, pre + "4.weight", pre + "4.bias")
+        dpre1 = _empty((rows, d), T, dq)
+        ops.layernorm_bwd(da3, h1, m3, r3, Wf[pre + "3.weight"], Gr[pre + "3.weight"], Gr[pre + "3.bias"], rows, d,
+                          dx_lp=dpre1, act=ACT_GELU_ERF_BWD, act_aux=pre1)
+        da0 = self._linear_bwd(dpre1, a0, pre + "1.weight", pre + "1.bias")
+        if group > 0:
+            ops.layernorm_bwd(da0, ft, m0, r0, Wf[pre + "0.weight"], Gr[pre + "0.weight"], Gr[pre + "0.bias"], rows, ftdim,
+                              dx_f32=dstream_f32, dx_lp=dstream_lp, group=group, skip=skip)
+            return None
+        dwords = _empty((rows, ftdim), torch.float32, dq)
+        ops.layernorm_bwd(da0, ft, m0, r0, Wf[pre + "0.weight"], Gr[pre + "0.weight"], Gr[pre + "0.bias"], rows, ftdim,
+                          dx_f32=dwords)
+        return dwords
+
+    def fdt_fwd(self, q, B, Tn, mask, temperature, save):
+        """codebook scores -> token pooling -> sparsemax/softmax -> weighted codebook sum (clip_fdt.py:113-154)."""
+        cfg, Wf = self.cfg, self.Wf
+        sd = Wf["space_dict"]
+        Cn, d = sd.shape
+        scores = _empty((B * Tn, Cn), torch.float32, q)
+        ops.gemm(q, self._mat("space_dict"), scores)
+        pooled = _empty((B, Cn), torch.float32, q)
+        pool = POOLS[cfg["pool"]]
+        argmax = _empty((B, Cn), torch.int32, q) if pool == POOL_MAX else None
+        ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool)
+        del scores
+        att_w = torch.empty_like(pooled)
+        if cfg["att_func"] == "sparsemax":
+            ops.sparsemax_fwd(pooled, att_w)
+        elif cfg["att_func"] == "softmax":
+            ops.softmax_fwd(pooled, att_w)
+        else:
+            raise NotImplementedError("att_func_type=%r has no HIP kernel (supported: sparsemax, softmax)" % cfg["att_func"])
+        att_ft = _empty((B, d), torch.float32, q)
+        ops.gemm(att_w, sd, att_ft, trans_b=True)
+        return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn) if save else None)
+
+    def fdt_bwd(self, saved, datt_ft):
+        """Returns dq [B*Tn, d] in T; accumulates d space_dict."""
+        q, argmax, mask, att_w, temperature, B, Tn = saved
+        cfg, Wf, Gr, T = self.cfg, self.Wf, self.Gr, self.T
+        sd = Wf["space_dict"]
+        Cn, d = sd.shape
+        need_sd = self.req["space_dict"]
+        datt_w = torch.empty_like(att_w)
+        ops.gemm(datt_ft, sd, datt_w)                                      # [B,d] . sd[C,d]^T
+        if need_sd:
+            ops.gemm(att_w, datt_ft, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True)   # att_w^T datt_ft
+        dpooled = torch.empty_like(att_w)
+        (ops.sparsemax_bwd if cfg["att_func"] == "sparsemax" else ops.softmax_bwd)(att_w, datt_w, dpooled)
+        dscores = _empty((B * Tn, Cn), T, q)
+        ops.fdt_pool_bwd(dpooled, argmax, mask, dscores, B, Tn, Cn, math.sqrt(d), temperature, POOLS[cfg["pool"]])
+        if need_sd:
+            ops.gemm(dscores, q, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True,
+                     split_k=ops.wgrad_split(Cn, d, B * Tn, 128 if T == torch.bfloat16 else 64))
+        dq = _empty((B * Tn, d), T, q)
+        ops.gemm(dscores, self._mat("space_dict"), dq, trans_b=True)
+        return dq
+
+    # ------------------------------------------------------------------ contrastive head
+    def head_fwd(self, img_ft, txt_ft, eps_i, eps_t, save):
+        """L2-normalise, temperature, global-batch gather, two logit matrices (clip_fdt.py:410-422 / clip.py:133-147).
+        img_ft, txt_ft: fp32 [B,D].  Returns logits_per_image, logits_per_text fp32 [B, W*B]."""
+        from . import comm
+        Wf = self.Wf
+        B, D = img_ft.shape
+        img_n = torch.empty_like(img_ft); ni = _empty((B,), torch.float32, img_ft)
+        txt_n = torch.empty_like(txt_ft); nt = torch.empty_like(ni)
+        ops.l2norm_fwd(img_ft, img_n, ni, eps_i)
+        ops.l2norm_fwd(txt_ft, txt_n, nt, eps_t)
+        scale = _empty((1,), torch.float32, img_ft)
+        ops.logit_scale_fwd(Wf["logit_scale"], scale, 100.0)
+        g_img, g_txt = comm.gather_pair(img_n, txt_n)
+        Bg = g_img.shape[0]
+        li = _empty((B, Bg), torch.float32, img_ft); lt = torch.empty_like(li)
+        ops.gemm(img_n, g_txt, li, alpha_ptr=scale)
+        ops.gemm(txt_n, g_img, lt, alpha_ptr=scale)
+        saved = (img_ft, txt_ft, img_n, txt_n, ni, nt, scale, g_img, g_txt, li, lt, eps_i, eps_t) if save else None
+        return li, lt, saved
+
+    def head_bwd(self, saved, dli, dlt):
+        """Returns (d img_ft, d txt_ft) fp32 [B,D]; accumulates d logit_scale."""
+        from . import comm
+        img_ft, txt_ft, img_n, txt_n, ni, nt, scale, g_img, g_txt, li, lt, eps_i, eps_t = saved
+        B, D = img_ft.shape
+        Bg = g_img.shape[0]
+        dli = dli.contiguous(); dlt = dlt.contiguous()
+        d_img_n = torch.empty_like(img_n); d_txt_n = torch.empty_like(txt_n)
+        ops.gemm(dli, g_txt, d_img_n, trans_b=True, alpha_ptr=scale)          # dli [B,Bg] . g_txt [Bg,D]
+        ops.gemm(dlt, g_img, d_txt_n, trans_b=True, alpha_ptr=scale)
+        dg_txt = _empty((Bg, D), torch.float32, img_ft); dg_img = torch.empty_like(dg_txt)
+        ops.gemm(dli, img_n, dg_txt, trans_a=True, trans_b=True, alpha_ptr=scale)   # dli^T [Bg,B] . img_n [B,D]
+        ops.gemm(dlt, txt_n, dg_img, trans_a=True, trans_b=True, alpha_ptr=scale)
+        s_img, s_txt = comm.reduce_gathered(dg_img, dg_txt, B)
+        d_img_n += s_img           # own slice of the gathered-matrix gradient (memory op on [B,D])
+        d_txt_n += s_txt
+        if self.req["logit_scale"]:
+            ops.logit_scale_bwd(dli, li, dlt, lt, self.Wf["logit_scale"], scale, self.Gr["logit_scale"])
+        d_img = torch.empty_like(img_ft); d_txt = torch.empty_like(txt_ft)
+        ops.l2norm_bwd(img_ft, ni, d_img_n, d_img, eps_i)
+        ops.l2norm_bwd(txt_ft, nt, d_txt_n, d_txt, eps_t)
+        return d_img, d_txt

@@ -1,0 +1,84 @@
+"""Shared host logic of the two contrastive models: engine ownership, text input handling, the single
+autograd node that wraps a whole forward/backward of the hot path."""
+import os
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...engine import Engine
+
+
+def default_precision():
+    return os.environ.get("ILVLM_PRECISION", "bf16")
+
+
+class _StepFn(torch.autograd.Function):
+    """One autograd node for the whole model forward.  Parameters are inputs only so that autograd schedules the
+    backward; their gradients are accumulated straight into the gradient arena by the kernels (returned as None)."""
+
+    @staticmethod
+    def forward(ctx, model, images, tokens, pad_mask, *params):
+        li, lt, saved = model._forward_impl(images, tokens, pad_mask, True)
+        ctx.model, ctx.saved, ctx.n = model, saved, len(params)
+        return li, lt
+
+    @staticmethod
+    def backward(ctx, dli, dlt):
+        saved, ctx.saved = ctx.saved, None
+        if saved is None:
+            raise RuntimeError("ilvlm: backward through the same forward twice is not supported")
+        li = saved["head"][9]
+        dli = torch.zeros_like(li) if dli is None else dli
+        dlt = torch.zeros_like(li) if dlt is None else dlt
+        ctx.model._backward_impl(saved, dli, dlt)
+        return (None,) * (4 + ctx.n)
+
+
+class ContrastiveBase(nn.Module):
+    def _init_engine(self, cfg):
+        object.__setattr__(self, "_eng", Engine(self, cfg))
+        object.__setattr__(self, "_grad_sync", None)     # set by the data-parallel wrapper
+
+    @property
+    def engine(self):
+        return self._eng
+
+    def _text_inputs(self, texts, device):
+        """list[str] (tokenised here, as the reference does inside forward) or a (tokens, pad_mask) pair."""
+        if isinstance(texts, (tuple, list)) and len(texts) == 2 and torch.is_tensor(texts[0]):
+            tokens, pad_mask = texts
+        elif hasattr(texts, "out1"):
+            tokens, pad_mask = texts.out1, texts.out2
+        else:
+            tokens, pad_mask = self.encode_text.tokenize(texts, context_length=self.encode_text.context_length)
+        tokens = tokens.to(device=device, dtype=torch.int64).contiguous()
+        pad_mask = pad_mask.to(device=device, dtype=torch.float32).contiguous()
+        return tokens, pad_mask
+
+    def _run(self, images, texts):
+        eng = self._eng
+        eng.prepare()
+        dev = eng.arena.P.device
+        if not images.is_cuda:
+            raise RuntimeError("images must be on the GPU (the solver calls image.cuda())")
+        tokens, pad_mask = self._text_inputs(texts, dev)
+        params = [p for _, p in eng.arena.named]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _StepFn.apply(self, images, tokens, pad_mask, *params)
+        li, lt, _ = self._forward_impl(images, tokens, pad_mask, False)
+        return li, lt
+
+    def all_gather(self, input):
+        from ... import comm
+        return comm.gather_pair(input, input)[0]
+
+    def zero_grad(self, set_to_none=False):
+        if self._eng.arena is not None:
+            self._eng.arena.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    def _sync(self, what):
+        if self._grad_sync is not None:
+            self._grad_sync(what)

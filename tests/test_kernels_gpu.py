@@ -49,6 +49,7 @@ def test_fragment_maps():
 
 
 GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1000, 768, 512), (256, 256, 1032)]
+GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -68,6 +69,21 @@ def test_gemm_plain(dtype, ta, tb, M, N, K):
         outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         ops.gemm(A, B, outb, trans_a=bool(ta), trans_b=bool(tb))
         assert rel(outb, want) < 1e-2
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES_F32_ODD)
+def test_gemm_f32_odd_leading_dimensions(ta, tb, M, N, K):
+    """logit matrices of odd local batch sizes: leading dimensions that are not multiples of 4"""
+    ops = _ops()
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    want = a @ b.t()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(dev(a.t() if ta else a), dev(b.t() if tb else b), out, trans_a=bool(ta), trans_b=bool(tb))
+    assert rel(out, want) < 2e-5
+    acc = torch.ones(M, N, device="cuda")
+    ops.gemm(dev(a.t() if ta else a), dev(b.t() if tb else b), acc, trans_a=bool(ta), trans_b=bool(tb), accumulate=True)
+    assert rel(acc, want + 1) < 2e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
