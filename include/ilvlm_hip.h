@@ -72,10 +72,16 @@ typedef struct ilvlm_gemm_epilogue {
     int out_dtype;          /* ILVLM_F32 / ILVLM_BF16 (bf16 only with compute_dtype bf16) */
     int accumulate;         /* 0 store, 1 fp32 atomic += */
     int out_group, out_skip;
+    float* a_rowsum;        /* optional [M]: += sum_k A(m,k) (bias gradient fused into the weight-gradient GEMM:
+                               A = dY^T); needs accumulate = 1, bf16 compute, K % 64 == 0, M % 8 == 0 */
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
+/* bf16 kernel selection (tuning / tests): 0 register-staged general kernel, 1 direct-to-LDS single buffer,
+ * (default) and 2 direct-to-LDS double buffer.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
+ * K-strided operands) always use the general kernel. */
+int ilvlm_gemm_set_variant(int variant);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-5 affine; base_transformer.py:10-18, clip_fdt.py:86-92) ----
  * y[r,:] = (x[R,:] - mean) * rstd * gamma + beta, R = map(r) when in_group > 0 (row remap as above:
@@ -89,7 +95,9 @@ int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const fl
 int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                         const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
                         int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
-                        int cols, int group, int skip, void* stream);
+                        int cols, int group, int skip, float* ws, int ws_blocks, void* stream);
+/* ws: optional workspace of 2 * ws_blocks * cols floats: per-workgroup dgamma/dbeta partials are written there and
+ * summed by a second tiny kernel (deterministic, no atomic contention); ws == NULL falls back to fp32 atomics. */
 
 /* ---- multi-head self attention core, head_dim 64 (F.multi_head_attention_forward math path reached
  * from base_transformer.py:45-48 / text_encoder/base_transformer.py:45-48; additive causal mask

@@ -258,6 +258,165 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
         }
 }
 
+
+// =====================================================================================
+// bf16 fast path: operands DMA'd straight into LDS with global_load_lds_dwordx4 (no VGPR staging).  The LDS images
+// are lane-linear per wave instruction (1 KiB = 64 lanes x 16 B), so the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and undone by the same XOR on the fragment read:
+//   K-contiguous operand : [128 rows][64 k] 128-byte rows, 16-byte chunk c of row r stored at slot c ^ (r & 7)
+//   K-strided operand    : [64 k][128 rows] 256-byte rows, chunk c of k-row r stored at slot c ^ swz(r),
+//                          swz(r) = ((r & 3) << 2) | ((r >> 2) & 3)  (conflict-free for ds_read_b64_tr_b16)
+// Requirements (checked on the host): K % 64 == 0; a K-strided operand needs rows % 8 == 0.
+// NBUF = 2: tile t+1 is in flight while tile t is multiplied; NBUF = 1: more workgroups per CU instead.
+// =====================================================================================
+__device__ __forceinline__ int swz16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+template <bool TR>
+__device__ __forceinline__ void glds_tile(const bf16* __restrict__ src, int ld, int r0, int k0, int R, unsigned char* tile,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int seg = wave * 4 + j;      // 1 KiB segment of the 16 KiB tile
+        const int s = seg * 64 + lane;     // 16-byte slot this lane fills
+        const bf16* g;
+        if (!TR) {
+            const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
+            g = src + (long)min(r0 + row, R - 1) * ld + k0 + chunk * 8;
+        } else {
+            const int kr = s >> 4, chunk = (s & 15) ^ swz16(kr);
+            g = src + (long)(k0 + kr) * ld + min(r0 + chunk * 8, R - 8);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(tile + seg * 1024), 16, 0, 0);
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 glds_frag(const unsigned char* tile, int r16, int k32, int lane) {
+    if (!TR) {
+        const int row = r16 + (lane & 15), chunk = (k32 >> 3) + (lane >> 4);
+        return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+        const int kr = k32 + 8 * g + q, c = (r16 >> 3) + (p >> 1), half = 8 * (p & 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + 256 * kr + 16 * (c ^ swz16(kr)) + half));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_s16x4*)(tile + 256 * (kr + 4) + 16 * (c ^ swz16(kr + 4)) + half));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        return u.v;
+    }
+}
+
+template <bool TA, bool TB, bool SWAP, int NBUF>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                             int ldb, int K, int tiles_m, int tiles_n, int split_k,
+                                                             EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = tiles_m * tiles_n * split_k;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int z = wg % split_k; wg /= split_k;
+    const int tn = wg % tiles_n, tm = wg / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nt_total = K / BK;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0, 0, 0, 0};
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
+    unsigned char* As0 = smem_raw;
+    unsigned char* Bs0 = smem_raw + 16384;
+    glds_tile<TA>(A, lda, m0, t_begin * BK, ep.M, As0, wave, lane);
+    glds_tile<TB>(B, ldb, n0, t_begin * BK, ep.N, Bs0, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const unsigned char* as = smem_raw + (NBUF == 2 ? cur * 32768 : 0);
+        const unsigned char* bs = as + 16384;
+        if (NBUF == 2 && t + 1 < t_end) {
+            unsigned char* an = smem_raw + (cur ^ 1) * 32768;
+            glds_tile<TA>(A, lda, m0, (t + 1) * BK, ep.M, an, wave, lane);
+            glds_tile<TB>(B, ldb, n0, (t + 1) * BK, ep.N, an + 16384, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = glds_frag<TA>(as, wm * 64 + i * 16, ks * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = glds_frag<TB>(bs, wn * 64 + j * 16, ks * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            if (rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (t + 1 < t_end) {
+                glds_tile<TA>(A, lda, m0, (t + 1) * BK, ep.M, As0, wave, lane);
+                glds_tile<TB>(B, ldb, n0, (t + 1) * BK, ep.N, Bs0, wave, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (SWAP) {
+                epilogue4<bf16>(ep, m0 + wm * 64 + i * 16 + c, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], alpha);
+            } else {
+                const int n = n0 + wn * 64 + j * 16 + c;
+                if (n < ep.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                        if (m < ep.M)
+                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
+                    }
+                }
+            }
+        }
+        if (rowsum && c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
+            }
+        }
+    }
+}
+
 // =====================================================================================
 // fp32 kernel: 64x64x16 tile, 4 waves (2x2), each 32x32 = 2x2 tiles of 16x16x4
 // =====================================================================================
@@ -363,6 +522,21 @@ int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, i
     return ILVLM_OK;
 }
 
+template <bool TA, bool TB, bool SWAP, int NBUF>
+int launch_glds(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
+                hipStream_t s) {
+    auto kern = gemm_bf16_glds_kernel<TA, TB, SWAP, NBUF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * 32768);
+        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_glds: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(256), NBUF * 32768, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_glds");
+    return ILVLM_OK;
+}
+
 template <bool TA, bool TB>
 int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
                hipStream_t s) {
@@ -375,6 +549,10 @@ int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, 
 }
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+// 0 = register-staged general kernel only, 1 = direct-to-LDS single buffer (default: fastest on the ViT-B/32
+// shapes, benchmarks/gemm_bench.py), 2 = direct-to-LDS double buffer
+int g_gemm_variant = 1;
 
 }  // namespace
 
@@ -394,6 +572,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ILVLM_REQUIRE(!(epi->act && !epi->aux), "gemm: activation needs aux");
     ILVLM_REQUIRE(!(epi->rowbias && epi->out_group <= 0), "gemm: rowbias needs out_group");
     ILVLM_REQUIRE(epi->act >= 0 && epi->act <= ILVLM_ACT_GELU_ERF_BWD, "gemm: bad act %d", epi->act);
+    ILVLM_REQUIRE(!(epi->a_rowsum && !(epi->accumulate && compute_dtype == ILVLM_BF16)),
+                  "gemm: a_rowsum needs accumulate and bf16 compute");
     hipStream_t s = (hipStream_t)stream;
     EpiArgs ep;
     ep.e = *epi;
@@ -416,6 +596,25 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bf16* a = (const bf16*)A;
         const bf16* b = (const bf16*)B;
         const bool swap = !epi->accumulate;
+        const int variant = g_gemm_variant;
+        const bool fast = variant != 0 && (K % BK == 0) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
+                          (!trans_b || (N % 8 == 0 && N >= 8));
+        if (fast) {
+#define ILVLM_FAST(TA, TB)                                                                                   \
+    do {                                                                                                     \
+        if (variant == 1)                                                                                    \
+            return swap ? launch_glds<TA, TB, true, 1>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)            \
+                        : launch_glds<TA, TB, false, 1>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);          \
+        return swap ? launch_glds<TA, TB, true, 2>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)                \
+                    : launch_glds<TA, TB, false, 2>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);              \
+    } while (0)
+            if (!trans_a && !trans_b) ILVLM_FAST(false, false);
+            if (!trans_a && trans_b) ILVLM_FAST(false, true);
+            if (trans_a && !trans_b) ILVLM_FAST(true, false);
+            ILVLM_FAST(true, true);
+#undef ILVLM_FAST
+        }
+        ILVLM_REQUIRE(epi->a_rowsum == nullptr, "gemm: a_rowsum needs the direct-to-LDS path (K %% 64 == 0, M %% 8 == 0)");
 #define ILVLM_DISPATCH(TA, TB)                                                                       \
     return swap ? launch_bf16<TA, TB, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)               \
                 : launch_bf16<TA, TB, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)
@@ -435,4 +634,11 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     if (!trans_a && trans_b) return launch_f32<false, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     if (trans_a && !trans_b) return launch_f32<true, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     return launch_f32<true, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+}
+
+// tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
+extern "C" int ilvlm_gemm_set_variant(int variant) {
+    ILVLM_REQUIRE(variant >= 0 && variant <= 2, "gemm_set_variant: 0, 1 or 2");
+    g_gemm_variant = variant;
+    return ILVLM_OK;
 }

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx_f32, TLP* __restrict__ dx_lp, int act,
                                                      const TLP* __restrict__ act_aux, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, long rows, int cols, int group, int skip) {
+                                                     float* __restrict__ dbeta, long rows, int cols, int group, int skip,
+                                                     float* __restrict__ ws) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[MAXV], ab[MAXV];
@@ -132,11 +133,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
             __syncthreads();
             if (wave == 0 && c < cols) {
                 f32x4 t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-                float* dst = (pass == 0 ? dgamma : dbeta) + c;
+                if (ws) {   // stage 1 of the two-stage reduction: this workgroup's partial row
+                    *(f32x4*)(ws + ((long)blockIdx.x * 2 + pass) * cols + c) = t;
+                } else {
+                    float* dst = (pass == 0 ? dgamma : dbeta) + c;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(dst + j, t[j]);
+                    for (int j = 0; j < 4; ++j) atomicAdd(dst + j, t[j]);
+                }
             }
         }
+    }
+}
+
+// stage 2: dgamma[c] += sum_b ws[b][0][c], dbeta[c] += sum_b ws[b][1][c].  16 columns x 16 partial-row lanes per
+// workgroup so the loads of one column are spread over 16 threads and stay independent (latency-bound otherwise).
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int cols,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, by = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const int pass = blockIdx.y;
+    float s = 0.f;
+    if (c < cols) {
+#pragma unroll 4
+        for (int b = by; b < nblocks; b += 16) s += ws[((long)b * 2 + pass) * cols + c];
+    }
+    red[by][cx] = s;
+    __syncthreads();
+    if (by == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cx];
+        float* dst = pass == 0 ? dgamma : dbeta;
+        dst[c] += t;
     }
 }
 
@@ -166,20 +195,22 @@ extern "C" int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamm
 extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                                    const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
                                    int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
-                                   int cols, int group, int skip, void* stream) {
+                                   int cols, int group, int skip, float* ws, int ws_blocks, void* stream) {
     ILVLM_REQUIRE(dy && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
     ILVLM_REQUIRE(dx_f32 || dx_lp, "layernorm_bwd: no output requested");
     ILVLM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXV * 256, "layernorm_bwd: bad cols %d", cols);
     ILVLM_REQUIRE(act == 0 || ((act == ILVLM_ACT_QUICKGELU_BWD || act == ILVLM_ACT_GELU_ERF_BWD) && act_aux && dx_lp),
                   "layernorm_bwd: bad activation arguments");
     hipStream_t s = (hipStream_t)stream;
+    ILVLM_REQUIRE(ws == nullptr || ws_blocks > 0, "layernorm_bwd: ws_blocks must be positive");
     int blocks = ceil_div(rows, 4);
-    if (blocks > 1024) blocks = 1024;
+    const int cap = ws ? ws_blocks : 1024;
+    if (blocks > cap) blocks = cap;
     dim3 grid(blocks), block(256);
     const int lp = dx_lp ? dx_lp_dtype : ILVLM_F32;
 #define LN_BWD(TDY, TX, TLP)                                                                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, \
-                       dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip)
+                       dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip, ws)
     const int key = dy_dtype * 4 + x_dtype * 2 + lp;
     switch (key) {
         case 0: LN_BWD(float, float, float); break;
@@ -194,5 +225,9 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
     }
 #undef LN_BWD
     ILVLM_LAUNCH_CHECK("layernorm_bwd");
+    if (ws) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 16), 2), dim3(256), 0, s, ws, blocks, cols, dgamma, dbeta);
+        ILVLM_LAUNCH_CHECK("layernorm_bwd_reduce");
+    }
     return ILVLM_OK;
 }

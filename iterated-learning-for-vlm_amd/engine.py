@@ -47,6 +47,8 @@ class ParamArena:
         self.G = torch.zeros(off, device=dev, dtype=torch.float32)
         self.S = torch.zeros(off, device=dev, dtype=torch.bfloat16) if precision == "bf16" else None
         self.views, self.gviews, self.sviews = {}, {}, {}
+        self.inactive = set()     # parameters the loss never reaches (no gradient, untouched by the optimizer)
+        self.reducer = None       # comm.GradReducer installed by the data-parallel wrapper
         for n, p in self.named:
             o, k = self.offsets[n], p.numel()
             v = self.P[o:o + k].view(p.shape)
@@ -55,6 +57,7 @@ class ParamArena:
             self.views[n] = v
             self.gviews[n] = self.G[o:o + k].view(p.shape)
             p.grad = self.gviews[n]
+            p._ilvlm_arena = (self, n)
             if self.S is not None:
                 self.sviews[n] = self.S[o:o + k].view(p.shape)
 
@@ -77,6 +80,11 @@ class ParamArena:
 
     def zero_grad(self):
         self.G.zero_()
+
+    def wait_grads(self):
+        """Order the current stream after any in-flight gradient all-reduce."""
+        if self.reducer is not None:
+            self.reducer.wait()
 
     def range_of(self, prefix):
         """[begin, end) element range of the parameters whose name starts with prefix (contiguous by construction)."""
@@ -109,6 +117,7 @@ class Engine:
     def prepare(self):
         if self.arena is None:
             self.arena = ParamArena(self.m, self.precision)
+            self.arena.inactive = set(self.m.unused_parameter_names())
         else:
             self.arena.sync_in()
         self.arena.refresh_shadow()
@@ -127,10 +136,14 @@ class Engine:
         """dy: [M,N] T; x: [M,K] T.  Accumulates dW (and db) into the gradient arena, returns dx (T) or None."""
         M, N = dy.shape
         K = x.shape[1]
+        need_b = bname is not None and self.req[bname]
+        fuse_b = need_b and self.req[wname] and self.T == torch.bfloat16 and ops.rowsum_fusable(N, M)
         if self.req[wname]:
+            # dW[N,K] += dy^T x ; the bias gradient sum_m dy[m,:] rides along as the row sums of the A operand
             ops.gemm(dy, x, self.Gr[wname].reshape(N, -1), trans_a=True, trans_b=True, accumulate=True,
-                     split_k=ops.wgrad_split(N, K, M, 128 if self.T == torch.bfloat16 else 64))
-        if bname is not None and self.req[bname]:
+                     split_k=ops.wgrad_split(N, K, M, 128 if self.T == torch.bfloat16 else 64),
+                     a_rowsum=self.Gr[bname] if fuse_b else None)
+        if need_b and not fuse_b:
             ops.colsum(dy, self.Gr[bname])
         if not need_dx:
             return None

@@ -16,7 +16,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("rowbias", vp), ("residual", vp), ("aux", vp), ("alpha_ptr", vp),
                 ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
-                ("out_group", i32), ("out_skip", i32)]
+                ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp)]
 
 
 class AdamWHyper(C.Structure):
@@ -27,8 +27,9 @@ class AdamWHyper(C.Structure):
 # name -> argtypes; every entry point declared in include/ilvlm_hip.h (tests check the .so exports them all)
 SIGNATURES = {
     "ilvlm_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(GemmEpilogue), i32, vp],
+    "ilvlm_gemm_set_variant": [i32],
     "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
-    "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "ilvlm_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_embed_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -69,6 +70,9 @@ def load():
         raise RuntimeError(
             "libilvlm_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C iterated-learning-for-vlm_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; load it FIRST so this library binds to the same HIP runtime instance
+    # (loading /opt/rocm's copy first leaves torch and the kernels on different runtimes: "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.ilvlm_version.restype = i32
     lib.ilvlm_version.argtypes = []

@@ -47,8 +47,29 @@ def selftest_fragments():
 
 
 # ---------------------------------------------------------------------------------------------
+class GemmProfiler:
+    """Brackets every bf16 GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = []     # (start_event, end_event, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=float(sum(f for _, _, f in self.records)))
+
+
+_gemm_profiler = None
+
+
+def set_gemm_profiler(p):
+    global _gemm_profiler
+    _gemm_profiler = p
+
+
 def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, residual=None, aux=None, act=0,
-         alpha=1.0, alpha_ptr=None, accumulate=False, out_group=0, out_skip=0, split_k=1, M=None, N=None, K=None):
+         alpha=1.0, alpha_ptr=None, accumulate=False, out_group=0, out_skip=0, split_k=1, M=None, N=None, K=None,
+         a_rowsum=None):
     """out[m,n] = epilogue(sum_k A(m,k) B(n,k)); see ilvlm_gemm.  a, b: 2-D bf16 or fp32 (same dtype);
     out: 2-D.  With out_group > 0, `out` is the token-stream tensor the rows are mapped into."""
     if a.dtype != b.dtype:
@@ -78,11 +99,29 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
             raise RuntimeError("gemm: aux stride must equal out stride")
     if accumulate and out.dtype != torch.float32:
         raise RuntimeError("gemm: accumulate needs an fp32 output")
+    if a_rowsum is not None:
+        _chk(a_rowsum, "gemm.a_rowsum", torch.float32, (m,))
     epi = GemmEpilogue(_p(bias), _p(rowbias), _p(residual), _p(aux), _p(alpha_ptr), float(alpha), int(act), dt(out),
-                       int(bool(accumulate)), int(out_group), int(out_skip))
+                       int(bool(accumulate)), int(out_group), int(out_skip), _p(a_rowsum))
+    prof = _gemm_profiler if (_gemm_profiler is not None and a.dtype == torch.bfloat16) else None
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     L.check(L.load().ilvlm_gemm(dt(a), int(trans_a), int(trans_b), m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb,
                                 out.data_ptr(), ldc, C.byref(epi), int(split_k), _stream()), "gemm")
+    if prof is not None:
+        ev1.record()
+        prof.records.append((ev0, ev1, 2.0 * m * n * k))
     return out
+
+
+def gemm_set_variant(v):
+    L.check(L.load().ilvlm_gemm_set_variant(int(v)), "gemm_set_variant")
+
+
+def rowsum_fusable(m, k):
+    """True when a weight-gradient GEMM with output rows m and reduction k can also produce the bias gradient."""
+    return k % 64 == 0 and m % 8 == 0 and m >= 8
 
 
 def wgrad_split(out_rows, out_cols, k, tile=128):
@@ -99,12 +138,28 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, group=0, 
             "layernorm_fwd")
 
 
+LN_WS_BLOCKS = 512
+_ln_ws = {}
+
+
+def _ln_workspace(device, cols):
+    """per-device scratch for the two-stage dgamma/dbeta reduction (2 x LN_WS_BLOCKS x cols floats)"""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ln_ws.get(key)
+    if ws is None or ws.numel() < 2 * LN_WS_BLOCKS * cols:
+        ws = torch.empty(2 * LN_WS_BLOCKS * max(cols, 1024), device=device, dtype=torch.float32)
+        _ln_ws[key] = ws
+    return ws
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, rows, cols, dres=None, dx_f32=None, dx_lp=None, act=0,
-                  act_aux=None, group=0, skip=0):
+                  act_aux=None, group=0, skip=0, two_stage=True):
+    ws = _ln_workspace(dy.device, cols) if two_stage else None
     L.check(L.load().ilvlm_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), mean.data_ptr(), rstd.data_ptr(),
                                          gamma.data_ptr(), _p(dres), _p(dx_f32), _p(dx_lp),
                                          dt(dx_lp) if dx_lp is not None else 0, act, _p(act_aux), dgamma.data_ptr(),
-                                         dbeta.data_ptr(), rows, cols, group, skip, _stream()), "layernorm_bwd")
+                                         dbeta.data_ptr(), rows, cols, group, skip, _p(ws), LN_WS_BLOCKS, _stream()),
+            "layernorm_bwd")
 
 
 def attention_fwd(qkv, out, lse, B, Lq, H, causal):

@@ -28,6 +28,9 @@ class CLIP(ContrastiveBase):
     def dtype(self):
         return self.visual.conv1.weight.dtype
 
+    def unused_parameter_names(self):
+        return []
+
     def forward(self, images, texts):
         return self._run(images, texts)
 

@@ -65,6 +65,12 @@ class Clip_FDT(ContrastiveBase):
     def dtype(self):
         return self.visual.conv1.weight.dtype
 
+    def unused_parameter_names(self):
+        """Parameters the FDT loss never reaches (grad stays None in the reference, so AdamW never touches them):
+        the pooled-feature heads and logit_scale_sd."""
+        return ["logit_scale_sd", "visual.proj", "visual.ln_post.weight", "visual.ln_post.bias",
+                "encode_text.text_projection.weight", "encode_text.text_projection.bias"]
+
     # ---------------------------------------------------------------- hot path
     def forward(self, images, texts):
         li, lt = self._run(images, texts)

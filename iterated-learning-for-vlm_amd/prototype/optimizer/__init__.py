@@ -1,0 +1,139 @@
+"""Optimizer registry (reference prototype/optimizer/__init__.py:18-26).  'AdamW' resolves to the fused
+multi-tensor HIP AdamW over the parameter arena; its param_groups / state / state_dict() keep
+torch.optim.AdamW's layout ('step', 'exp_avg', 'exp_avg_sq') so reference checkpoints round-trip."""
+import ctypes as C
+
+import torch
+
+from ... import lib as L
+
+CHUNK = 4096
+INACTIVE_GROUP = 15
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad=True is not used by the reference configs")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False))
+        if len(self.param_groups) >= INACTIVE_GROUP:
+            raise ValueError("at most %d parameter groups" % (INACTIVE_GROUP - 1))
+        self._arena = None
+        self._sig = None
+        self._step = 0
+        self._pending_state = False
+
+    # -- arena binding -----------------------------------------------------------------------
+    def _bind(self):
+        arena = None
+        for g in self.param_groups:
+            for p in g["params"]:
+                a = getattr(p, "_ilvlm_arena", None)
+                if a is None:
+                    raise RuntimeError("FusedAdamW: parameter is not owned by an ilvlm engine arena (run one forward of "
+                                       "the model on the GPU before optimizer.step())")
+                if arena is None:
+                    arena = a[0]
+                elif arena is not a[0]:
+                    raise RuntimeError("FusedAdamW: parameters of several models in one optimizer are not supported")
+        self._arena = arena
+        self.M = torch.zeros_like(arena.P)
+        self.V = torch.zeros_like(arena.P)
+
+    def _views(self, p):
+        arena, name = p._ilvlm_arena
+        o = arena.offsets[name]
+        return self.M[o:o + p.numel()].view(p.shape), self.V[o:o + p.numel()].view(p.shape)
+
+    def _build_table(self):
+        arena = self._arena
+        sig = tuple(tuple(bool(p.requires_grad) and (p._ilvlm_arena[1] not in arena.inactive) for p in g["params"])
+                    for g in self.param_groups)
+        if sig == self._sig:
+            return
+        offs, cnts, grps = [], [], []
+        for gi, g in enumerate(self.param_groups):
+            for p, act in zip(g["params"], sig[gi]):
+                o, n = arena.offsets[p._ilvlm_arena[1]], p.numel()
+                for c in range(0, n, CHUNK):
+                    offs.append(o + c)
+                    cnts.append(min(CHUNK, n - c))
+                    grps.append(gi if act else INACTIVE_GROUP)
+                if act and p not in self.state:
+                    m, v = self._views(p)
+                    self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=m, exp_avg_sq=v)
+        dev = arena.P.device
+        self._coff = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._ccnt = torch.tensor(cnts, dtype=torch.int32, device=dev)
+        self._cgrp = torch.tensor(grps, dtype=torch.int32, device=dev)
+        self._sig = sig
+
+    def _ingest_loaded_state(self):
+        """After load_state_dict: copy the loaded moments into the arenas and re-point the state at the views."""
+        steps = [0]
+        for p, st in list(self.state.items()):
+            m, v = self._views(p)
+            if st["exp_avg"].data_ptr() != m.data_ptr():
+                m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+            steps.append(int(float(st["step"])))
+        self._step = max(steps)
+        self._pending_state = False
+
+    # -- torch.optim.Optimizer surface ---------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        """Zeroes the flat gradient arena with one memset (gradient views stay attached)."""
+        if self._arena is None:
+            try:
+                self._bind()
+            except RuntimeError:
+                return super().zero_grad(set_to_none=False)
+        self._arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        if self._arena is None:
+            self._bind()
+        if self._pending_state:
+            self._ingest_loaded_state()
+        arena = self._arena
+        arena.wait_grads()
+        self._build_table()
+        self._step += 1
+        h = L.AdamWHyper()
+        b1 = b2 = eps = None
+        for gi, g in enumerate(self.param_groups):
+            h.lr[gi], h.weight_decay[gi], h.active[gi] = float(g["lr"]), float(g["weight_decay"]), 1
+            if b1 is None:
+                (b1, b2), eps = g["betas"], g["eps"]
+            elif (b1, b2) != tuple(g["betas"]) or eps != g["eps"]:
+                raise NotImplementedError("per-group betas/eps are not supported by the fused kernel")
+        h.active[INACTIVE_GROUP] = 0
+        h.beta1, h.beta2, h.eps, h.step = float(b1), float(b2), float(eps), self._step
+        L.check(L.load().ilvlm_adamw_step(arena.P.data_ptr(), arena.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                          arena.S.data_ptr() if arena.S is not None else None, self._coff.data_ptr(),
+                                          self._ccnt.data_ptr(), self._cgrp.data_ptr(), int(self._coff.numel()), C.byref(h),
+                                          torch.cuda.current_stream().cuda_stream), "adamw_step")
+
+    def state_dict(self):
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._pending_state = True
+        if self._arena is not None:
+            self._ingest_loaded_state()
+
+
+AdamW = FusedAdamW
+
+
+def optim_entry(config):
+    kwargs = dict(config["kwargs"])
+    if config["type"] != "AdamW":
+        raise NotImplementedError("optimizer type %r: only AdamW (the shipped configs' choice) runs on the HIP path" % config["type"])
+    return FusedAdamW(**kwargs)

@@ -1,0 +1,88 @@
+"""Process-group setup and the data-parallel wrapper (reference prototype/utils/torch_ddp_dist.py:9-67).
+
+One process per GPU, torchrun env contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), backend
+'nccl' (= RCCL over xGMI on MI355X).  convert_to_ddp_model returns a wrapper exposing `.module` like torch DDP, but
+gradient averaging is done on the flat gradient arena: the text-tower range is all-reduced on a side stream while the
+vision tower is still in backward, the rest when backward ends; unused and frozen parameters ride along as zeros
+(the reference needs find_unused_parameters=True for them)."""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as distributed
+from torch import nn
+
+from ... import comm
+
+
+def get_world_size():
+    return int(os.environ.get("WORLD_SIZE", 1))
+
+
+def get_local_rank():
+    return int(os.environ.get("LOCAL_RANK", 0))
+
+
+def get_rank():
+    return int(os.environ.get("RANK", 0))
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def set_random_seed(seed=0):
+    """seed 0 on every rank, as the reference does (:21-27)"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.random.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def init_ddp(backend="nccl"):
+    local_rank, world_size, rank = get_local_rank(), get_world_size(), get_rank()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", random.randint(6000, 60000)))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    distributed.init_process_group(backend=backend, init_method="tcp://%s:%d" % (addr, port), world_size=world_size,
+                                   rank=rank)
+
+
+class NativeDDP(nn.Module):
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        module._eng.prepare()                      # adopt the parameters into the arena now
+        arena = module._eng.arena
+        if comm.world()[1] > 1:
+            distributed.broadcast(arena.P, 0)      # ONE flattened broadcast (reference: one per state_dict tensor)
+        arena.reducer = comm.GradReducer(arena.G)
+        a = arena
+        t0, t1 = a.range_of("encode_text.")
+        q0, q1 = a.range_of("txt_query_model.")
+        self._early = [(t0, t1), (q0, q1)]
+        rest, cur = [], 0
+        for b, e in sorted(self._early):
+            if b > cur:
+                rest.append((cur, b))
+            cur = max(cur, e)
+        if cur < a.total:
+            rest.append((cur, a.total))
+        self._late = rest
+        object.__setattr__(module, "_grad_sync", self._on_sync)
+
+    def _on_sync(self, what):
+        red = self.module._eng.arena.reducer
+        for b, e in (self._early if what == "text_done" else self._late):
+            red.reduce_range(b, e)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def convert_to_ddp_model(model, local_rank=None, find_unused_parameters=True):
+    return NativeDDP(model)

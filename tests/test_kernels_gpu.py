@@ -52,6 +52,36 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1
 GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 392, 256), (136, 2304, 768), (8, 8, 128)])
+def test_gemm_direct_to_lds_variants(variant, ta, tb, M, N, K):
+    """the global_load_lds kernels (single / double buffered), incl. ragged M/N tiles, split-K and the fused
+    bias-gradient row sum"""
+    ops = _ops()
+    a, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2).to(torch.bfloat16)
+    want = a.float() @ b.float().t()
+    A, B = dev(a.t() if ta else a), dev(b.t() if tb else b)
+    try:
+        ops.gemm_set_variant(variant)
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(A, B, out, trans_a=bool(ta), trans_b=bool(tb))
+        assert rel(out, want) < 2e-5
+        outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, B, outb, trans_a=bool(ta), trans_b=bool(tb), bias=dev(rnd(N, seed=3)))
+        assert rel(outb, want + rnd(N, seed=3)) < 1e-2
+        for split in (1, 3):
+            acc = torch.ones(M, N, device="cuda")
+            rs = torch.ones(M, device="cuda")
+            ops.gemm(A, B, acc, trans_a=bool(ta), trans_b=bool(tb), accumulate=True, split_k=split,
+                     a_rowsum=rs if M % 8 == 0 else None)
+            assert rel(acc, want + 1) < 2e-5
+            if M % 8 == 0:
+                assert rel(rs, 1 + a.float().sum(1)) < 2e-5
+    finally:
+        ops.gemm_set_variant(2)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -143,7 +173,7 @@ def test_gemm_rejects_bad_arguments():
                                      (torch.bfloat16, torch.bfloat16)])
 def test_layernorm(cols, xdt, ydt):
     ops = _ops()
-    rows = 101
+    rows = 101 if cols != 768 else 5003      # 5003 rows: more rows than workgroups x 4 (grid-stride + workspace cap)
     x = (rnd(rows, cols, seed=1) * 3 + 0.5).to(xdt)
     w, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
     xr = x.float().requires_grad_(True)
@@ -161,10 +191,13 @@ def test_layernorm(cols, xdt, ydt):
     dg, db = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
     dx32 = torch.empty(rows, cols, device="cuda")
     dxlp = torch.empty(rows, cols, device="cuda", dtype=ydt)
-    ops.layernorm_bwd(dev(dy), X, mean, rstd, W_, dg, db, rows, cols, dres=dev(dres), dx_f32=dx32, dx_lp=dxlp)
-    assert rel(dx32, xr.grad + dres) < 2e-5
-    assert rel(dxlp, xr.grad + dres) < tol
-    assert rel(dg, wr.grad) < 2e-5 and rel(db, br.grad) < 2e-5
+    for two_stage in (True, False):     # workspace reduction and the atomic fallback; both accumulate ("+=")
+        dg.fill_(1.0); db.fill_(1.0)
+        ops.layernorm_bwd(dev(dy), X, mean, rstd, W_, dg, db, rows, cols, dres=dev(dres), dx_f32=dx32, dx_lp=dxlp,
+                          two_stage=two_stage)
+        assert rel(dx32, xr.grad + dres) < 2e-5
+        assert rel(dxlp, xr.grad + dres) < tol
+        assert rel(dg, 1 + wr.grad) < 2e-5 and rel(db, 1 + br.grad) < 2e-5
 
 
 def test_layernorm_row_remap_and_act():
