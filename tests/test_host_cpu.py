@@ -1,0 +1,118 @@
+"""CPU tests of the host logic that mirrors the reference's interfaces: LR schedule, parameter grouping, state_dict
+layout, iterated-learning reset, config parsing.  Pinned by fixtures generated from the reference (tests/golden)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from configs import CFG, FDT_VARIANTS, model_kwargs, state_shapes, VITB32
+from detfill import det_state, probe
+
+PCONFIG = dict(bn_w=dict(weight_decay=0), bn_b=dict(weight_decay=0), ln_w=dict(weight_decay=0), ln_b=dict(weight_decay=0),
+               bias=dict(weight_decay=0), logit_scale=dict(weight_decay=0))
+
+
+def full_kwargs(fdt):
+    kw = dict(image_encode=dict(embed_dim=512),
+              text_encode=dict(bpe_path=None, text_encode_type="Transformer", text_model_utils=dict(random=False, freeze=False),
+                               embed_dim=512))
+    if fdt:
+        kw["fdt"] = dict(sd_temperature=1000, att_func_type="sparsemax", pool_type="max", use_allgather=True, sd_num=4096,
+                         sd_dim=512, raw_img_ft_dim=768, raw_txt_ft_dim=512)
+    else:
+        kw["clip"] = dict(use_allgather=True)
+    return kw
+
+
+def test_cosine_schedule_matches_reference_table(golden_dir):
+    from ilvlm_amd.prototype.lr_scheduler import scheduler_entry
+    g = np.load(os.path.join(golden_dir, "g6_lr_table.npz"))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([dict(params=[p], lr=5e-5), dict(params=[torch.nn.Parameter(torch.zeros(1))], lr=1e-5)], lr=5e-5)
+    sch = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=opt, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
+                                                          warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
+    for s, want in zip(g["steps"], g["lrs"]):
+        sch.step(int(s))
+        lr0, lr1 = sch.get_lr()
+        assert abs(lr0 - want) <= 1e-12 * max(want, 1e-30) + 1e-25
+        assert abs(lr1 - want / 5) <= 1e-12 * max(want, 1e-30) + 1e-25      # every group scales with its own initial lr
+
+
+@pytest.mark.parametrize("mtype,fdt", [("clip_fdt_vitb32", True), ("clip_vitb32", False)])
+def test_state_dict_layout_and_param_groups_match_reference(golden_dir, mtype, fdt):
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.utils.misc import param_group_all
+    with open(os.path.join(golden_dir, "g7_param_groups.json")) as f:
+        g = json.load(f)[mtype]
+    model = model_entry(dict(type=mtype, kwargs=full_kwargs(fdt)))
+    model.train()
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == [(k, s) for k, s in g["state_dict"]]
+    assert not model.visual.conv1.weight.requires_grad          # frozen by train()
+    groups = param_group_all(model, PCONFIG)[0]
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    assert [[id2name[id(p)] for p in gr["params"]] for gr in groups] == [gr["names"] for gr in g["groups"]]
+    assert [gr.get("weight_decay") for gr in groups] == [gr["weight_decay"] for gr in g["groups"]]
+
+
+def test_reset_text_encoder_matches_reference(golden_dir):
+    from ilvlm_amd.prototype.model import model_entry
+    g = np.load(os.path.join(golden_dir, "g8_reset.npz"))
+    c = CFG["a"]
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=model_kwargs(c, FDT_VARIANTS[0])))
+    st = det_state(state_shapes(c, True), 11)
+    model.load_state_dict({k: torch.from_numpy(a) for k, a in st.items()})
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    model.reset_text_encoder(6000)
+    changed = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
+    assert changed == json.loads(str(g["changed"]))
+    for k in changed:
+        np.testing.assert_allclose(probe(k, model.state_dict()[k].numpy()), g["after." + k], rtol=1e-6, atol=1e-7)
+    # embeddings and the attention in-projections are NOT reset
+    for k in ("encode_text.token_embedding.weight", "encode_text.positional_embedding",
+              "encode_text.transformer.resblocks.0.attn.in_proj_weight", "space_dict", "visual.proj"):
+        assert k not in changed
+
+
+def test_freeze_unfreeze_helpers():
+    from ilvlm_amd.prototype.model import model_entry
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=model_kwargs(CFG["a"], FDT_VARIANTS[0])))
+    model.train()
+    model.find_always_freeze_weight()
+    assert model.weight_always_freeze == ["visual.conv1.weight"]
+    model.freeze_unfreeze_vision_weights(unfreeze=False, freeze_codebook=True)
+    assert not any(p.requires_grad for p in model.visual.parameters())
+    assert not model.space_dict.requires_grad and not model.logit_scale.requires_grad
+    assert all(p.requires_grad for p in model.encode_text.parameters())
+    model.freeze_unfreeze_vision_weights(unfreeze=True, freeze_codebook=False)
+    # published-code behaviour kept: the freeze list holds FULL names, unfreeze compares encoder-relative names, so
+    # conv1 is unfrozen here and re-frozen by the next train() call (reference clip_fdt.py:285-290)
+    assert model.visual.conv1.weight.requires_grad
+    model.train()
+    assert not model.visual.conv1.weight.requires_grad and model.space_dict.requires_grad
+
+
+def test_parse_config_and_registry(tmp_path):
+    from ilvlm_amd.prototype.utils.misc import parse_config, EasyDict
+    from ilvlm_amd.prototype.model import model_entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = parse_config(os.path.join(root, "example", "clip_fdt", "config_cc3m.yaml"))
+    assert cfg.model.type == "clip_fdt_vitb32" and cfg.model.kwargs.fdt.sd_num == 4096
+    assert cfg.reset.reset_steps == 6000 and cfg.grad_clip.type == "logit_scale_param_value"
+    assert cfg.optimizer.kwargs.betas == [0.9, 0.98] and cfg.lr_scheduler.kwargs.warmup_steps == 500
+    cfg.data.train.batch_size = 64
+    assert cfg["data"]["train"]["batch_size"] == 64
+    base = parse_config(os.path.join(root, "example", "clip", "config_cc3m.yaml"))
+    assert base.model.type == "clip_vitb32"
+    small = EasyDict(type="clip_fdt_vitb32", kwargs=model_kwargs(CFG["b"], FDT_VARIANTS[0]))
+    m = model_entry(small)
+    assert m.img_query_model.temperature == 1000.0 and m.space_dict.shape == (320, 64)
+
+
+def test_product_path_refuses_to_run_on_cpu():
+    from ilvlm_amd.prototype.model import model_entry
+    c = CFG["a"]
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=model_kwargs(c, FDT_VARIANTS[0])))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 3, c["res"], c["res"]), (torch.zeros(2, c["ctx"], dtype=torch.long), torch.zeros(2, c["ctx"])))
