@@ -1,0 +1,317 @@
+"""Training solver for example/clip_fdt and example/clip on the MI355X engine.
+
+Restates the reference's ClsSolver (example/clip_fdt/train_solver.py:92-717, example/clip/train_solver.py:157-624):
+same CLI (--config --output_path --batch_size --debug --exp_name --ckpt_path), same YAML keys, same run-directory and
+checkpoint layout ({'model': DDP state_dict with the 'module.' prefix, 'optimizer', 'last_iter'} in
+<out>/checkpoints/ckpt_{step}.pth.tar), same step body order (train_solver.py:348-439) and the iterated-learning
+reset schedule (:545-557).  Differences, all deliberate:
+  * no per-step host synchronisation: the reference's three barrier()+.cpu() and three .item() per step
+    (linklink/__init__.py:30-34, misc.py:38-40) are replaced by device-side meters read every print_freq steps;
+  * the reset call passes seed=curr_step (the published call passes no seed and would raise TypeError at the
+    first reset, train_solver.py:546 vs clip_fdt.py:256) and the codebook copy is taken at the reset step (the
+    published code only stores it on resume, :548-549) -- SURVEY.md section 5;
+  * wandb, the webdataset pipeline and the in-loop SugarCrepe evaluation are outside the hot path: data comes from
+    `--synthetic` (the benchmark's generator) or from any iterable of (image[B,3,H,W], text) batches passed to
+    ClsSolver(train_data=...).
+"""
+import argparse
+import json
+import logging
+import os
+import pprint
+import time
+
+import torch
+
+from .prototype import linklink as link
+from .prototype.loss_functions import ClipInfoCELoss
+from .prototype.lr_scheduler import scheduler_entry
+from .prototype.model import model_entry
+from .prototype.optimizer import optim_entry
+from .prototype.utils import torch_ddp_dist as D
+from .prototype.utils.misc import (EasyDict, accuracy, count_params, create_logger, get_logger, load_state_model,
+                                   load_state_optimizer, makedir, param_group_all, parse_config)
+
+
+class DeviceMeter:
+    """Sliding-window mean kept on the device; read (one host sync) only when a log line is printed."""
+
+    def __init__(self, length, device):
+        self.buf = torch.zeros(max(1, length), device=device)
+        self.n = 0
+
+    def update(self, t):
+        self.buf[self.n % self.buf.numel()] = t.detach().reshape(())
+        self.n += 1
+
+    def read(self):
+        k = min(self.n, self.buf.numel())
+        if k == 0:
+            return 0.0, 0.0
+        window = self.buf[:k]
+        stats = torch.stack([self.buf[(self.n - 1) % self.buf.numel()], window.mean()])
+        if link.get_world_size() > 1 and torch.distributed.is_initialized():
+            link.allreduce(stats)            # values were pre-divided by world_size, as in the reference
+        val, avg = stats.tolist()
+        return val, avg
+
+
+class SyntheticPairs:
+    """Synthetic 224x224 + 77-token pairs, resident on the device."""
+
+    def __init__(self, batch_size, num_batches, res, ctx, device, seed=1234):
+        g = torch.Generator().manual_seed(seed + link.get_rank())
+        self.num_batches = num_batches
+        self.images = torch.randn(batch_size, 3, res, res, generator=g).to(device)
+        tok = torch.zeros(batch_size, ctx, dtype=torch.int64)
+        pad = torch.full((batch_size, ctx), float("-inf"))
+        lens = torch.randint(min(8, ctx), ctx + 1, (batch_size,), generator=g)
+        for b in range(batch_size):
+            n = int(lens[b])
+            tok[b, 0] = 49407
+            tok[b, 1:n - 1] = torch.randint(0, 49406, (n - 2,), generator=g)
+            tok[b, n - 1] = 49408
+            pad[b, :n] = 0
+        self.text = (tok.to(device), pad.to(device))
+
+    def set_epoch(self, epoch):
+        pass
+
+    def __iter__(self):
+        for _ in range(self.num_batches):
+            yield self.images, self.text
+
+    @property
+    def dataloader(self):
+        return self
+
+
+class ClsSolver:
+    def __init__(self, args, train_data=None):
+        self.args = args
+        self.config = parse_config(args.config)
+        self.config.output_path = args.output_path
+        self.config.data.train.batch_size = args.batch_size
+        self.fdt = "fdt" in self.config.model.kwargs
+        if "reset" not in self.config:
+            self.config.reset = EasyDict(enable=False, reset_steps=0, reset_nums=0, smooth_steps=0)
+        self.train_data = train_data
+        self.setup_env()
+        self.build_model()
+        self.build_optimizer()
+        self.build_data()
+        self.build_lr_scheduler()
+
+    # ------------------------------------------------------------------------------------------
+    def setup_env(self):
+        D.set_random_seed()
+        self.rank, self.world_size, self.local_rank = D.get_rank(), D.get_world_size(), D.get_local_rank()
+        rs = self.config.reset
+        exp = (self.args.exp_name or "") + "_Reset_%s_steps_%s_smooth_%s" % (rs.enable, rs.reset_steps, rs.smooth_steps)
+        if self.args.debug:
+            exp += "_debug"
+        self.output_path = os.path.join(self.config.output_path, exp)
+        self.save_path = os.path.join(self.output_path, "checkpoints")
+        self.result_path = os.path.join(self.output_path, "results")
+        for p in (self.output_path, self.save_path, self.result_path):
+            makedir(p)
+        create_logger(os.path.join(self.output_path, "log.txt"))
+        self.logger = get_logger(__name__)
+        self.logger.critical("config: %s" % pprint.pformat(self.config))
+        if self.rank == 0:
+            with open(os.path.join(self.output_path, "config.json"), "w") as f:
+                json.dump(self.config, f)
+        if self.args.ckpt_path:
+            self.state = torch.load(self.args.ckpt_path, map_location="cpu", weights_only=False)
+            self.logger.info("load ckpt from %s" % self.args.ckpt_path)
+        else:
+            self.state = {"last_iter": 0}
+
+    def build_model(self):
+        self.model = model_entry(self.config.model)
+        self.model.cuda()
+        count_params(self.model)
+        self.model = D.convert_to_ddp_model(self.model, self.local_rank)
+        if "model" in self.state:
+            load_state_model(self.model, self.state["model"])
+
+    def build_optimizer(self):
+        oc = self.config.optimizer
+        oc.kwargs.lr = self.config.lr_scheduler.kwargs.base_lr
+        pconfig = {}
+        if oc.get("no_wd", False):
+            for k in ("conv_b", "linear_b", "bn_w", "bn_b", "ln_w", "ln_b"):
+                pconfig[k] = {"weight_decay": 0.0}
+        if "pconfig" in oc:
+            pconfig.update(oc["pconfig"])
+        kwargs = dict(oc.kwargs)
+        kwargs["params"] = param_group_all(self.model, pconfig)[0]
+        self.optimizer = optim_entry(dict(type=oc.type, kwargs=kwargs))
+        if "optimizer" in self.state and not self.fdt:
+            # the baseline solver restores optimizer state (example/clip/train_solver.py:279-280); the FDT solver does not
+            load_state_optimizer(self.optimizer, self.state["optimizer"])
+
+    def build_lr_scheduler(self):
+        kw = dict(self.config.lr_scheduler.kwargs)
+        kw.setdefault("max_iter", self.config.data.get("max_iter", 0))
+        kw["last_iter"] = self.state["last_iter"]
+        kw["reset_steps"] = self.config.reset.reset_steps if self.fdt else kw.get("reset_steps", 0)
+        kw["optimizer"] = self.optimizer
+        self.lr_scheduler = scheduler_entry(dict(type=self.config.lr_scheduler.type, kwargs=kw))
+
+    def build_data(self):
+        if self.train_data is not None:
+            return
+        tc = self.config.data.train
+        if getattr(self.args, "synthetic", False) or tc.get("synthetic", False):
+            m = self.model.module
+            nb = self.args.max_steps or max(1, tc.num_samples // (tc.batch_size * self.world_size))
+            self.train_data = SyntheticPairs(tc.batch_size, nb, m.visual.input_resolution, m.encode_text.context_length,
+                                             torch.device("cuda", self.local_rank))
+            return
+        raise RuntimeError("the webdataset input pipeline of the reference (prototype/data) is outside the accelerated hot "
+                           "path: pass --synthetic, or construct ClsSolver(args, train_data=<iterable of (image, text)>)")
+
+    # ------------------------------------------------------------------------------------------
+    def store_codebook_value(self):
+        self.stored_codebook = self.model.module.space_dict.data.clone()
+
+    def keep_codebook_value(self):
+        self.model.module.space_dict.data.copy_(self.stored_codebook)
+
+    def _clamp_logit_scale(self):
+        gc = self.config.grad_clip
+        if gc.type == "logit_scale_param_value":
+            self.model.module.logit_scale.data.clamp_(min=gc.value, max=gc.max_value)
+        elif gc.type == "logit_scale_param_abs_min":
+            self.model.module.logit_scale.data.clamp_(min=gc.value)
+        elif gc.type == "constant":
+            self.model.module.logit_scale.requires_grad = False
+        else:
+            raise NotImplementedError("grad_clip.type=%r (shipped configs use logit_scale_param_value)" % gc.type)
+
+    def _temperature(self, curr_step):
+        td = self.config.get("t_decay")
+        if not (self.fdt and td) or curr_step % td.sd_T_decay_iter:
+            return
+        t = max(td.org_t * (td.sd_T_decay_w ** (curr_step / td.sd_T_decay_iter)), td.sd_T_min)
+        self.model.module.img_query_model.temperature = t
+        self.model.module.txt_query_model.temperature = t
+
+    def train_step(self, image, text, curr_step):
+        """One optimisation step in the reference's order (train_solver.py:348-439)."""
+        self.lr_scheduler.step(curr_step)
+        self._temperature(curr_step)
+        image = image.cuda(non_blocking=True)
+        out = self.model(image, text)
+        logits = out[0] if self.fdt else out
+        loss, target = self.criterion(logits[0], logits[1])
+        loss = loss / self.world_size
+        prec1, prec5 = accuracy(logits[0], target, topk=(1, self.topk))
+        self.optimizer.zero_grad()
+        self._clamp_logit_scale()
+        loss.backward()
+        self.optimizer.step()
+        self._clamp_logit_scale()
+        return loss, prec1 / self.world_size, prec5 / self.world_size
+
+    def save_checkpoint(self, curr_step):
+        if self.rank == 0:
+            name = "ckpt_%d.pth.tar" % curr_step if self.config.saver.save_many else "ckpt.pth.tar"
+            self.state["model"] = self.model.state_dict()
+            self.state["optimizer"] = self.optimizer.state_dict()
+            self.state["last_iter"] = curr_step
+            torch.save(self.state, os.path.join(self.save_path, name))
+            if curr_step % (self.config.saver.save_freq * 10) == 0:
+                k_path = self.save_path + "_k_times"
+                os.makedirs(k_path, exist_ok=True)
+                torch.save(self.state, os.path.join(k_path, "ckpt_%d.pth.tar" % curr_step))
+        link.barrier()
+
+    def iterated_learning(self, curr_step, start_step):
+        """train_solver.py:545-557 with the two documented fixes (module docstring)."""
+        rs = self.config.reset
+        if not (self.fdt and rs.enable and rs.reset_steps < curr_step < rs.reset_steps * rs.reset_nums):
+            return
+        m = self.model.module
+        phase = curr_step % rs.reset_steps
+        if phase == 0 or (curr_step == start_step + 1 and phase < rs.smooth_steps):
+            self.store_codebook_value()
+            m.reset_text_encoder(curr_step)
+            self.logger.info("step %d: reset text encoder" % curr_step)
+        elif phase < rs.smooth_steps:
+            self.keep_codebook_value()
+        if phase == rs.smooth_steps:
+            m.freeze_unfreeze_vision_weights(unfreeze=True, freeze_codebook=False)
+            m.train()          # re-freezes conv1 exactly as the next train()/eval() call does in the reference
+            self.logger.info("step %d: unfreeze vision encoder" % curr_step)
+
+    def train(self):
+        cfg = self.config
+        dev = torch.device("cuda", self.local_rank)
+        self.model.train()
+        self.criterion = ClipInfoCELoss()
+        self.model.module.find_always_freeze_weight()
+        self.topk = 5
+        pf = cfg.saver.print_freq
+        meters = {k: DeviceMeter(pf, dev) for k in ("loss", "top1", "top5")}
+        each_epoch = getattr(self.train_data.dataloader, "num_batches", None) or len(self.train_data.dataloader)
+        total_step = cfg.data.train.epoch * each_epoch
+        start_step = curr_step = self.state["last_iter"]
+        end = time.time()
+        losses = []
+        for epoch_id in range(cfg.data.train.epoch):
+            self.train_data.set_epoch(epoch_id)
+            for image, text in self.train_data.dataloader:
+                curr_step += 1
+                loss, p1, p5 = self.train_step(image, text, curr_step)
+                meters["loss"].update(loss); meters["top1"].update(p1); meters["top5"].update(p5)
+                if curr_step % pf == 0:
+                    lv, la = meters["loss"].read()
+                    _, t1 = meters["top1"].read()
+                    _, t5 = meters["top5"].read()
+                    bt = (time.time() - end) / pf
+                    end = time.time()
+                    ls = float(self.model.module.logit_scale.detach())
+                    losses.append(la)
+                    if self.rank == 0:
+                        self.logger.critical(
+                            "Iter: [%d/%d]\tTime %.3f\tLoss_all %.4f (%.4f)\tPrec@1 (%.3f)\tPrec@5 (%.3f)\tLR %.6f\t"
+                            "logit_scale_exp %.4f\tlogit_scale %.4f\tpairs/s %.1f" % (
+                                curr_step, total_step, bt, lv, la, t1, t5, self.lr_scheduler.get_lr()[0],
+                                float(torch.tensor(ls).exp()), ls, cfg.data.train.batch_size * self.world_size / max(bt, 1e-9)))
+                if curr_step % cfg.saver.save_freq == 0 or curr_step == total_step:
+                    self.save_checkpoint(curr_step)
+                self.iterated_learning(curr_step, start_step)
+                if self.args.max_steps and curr_step - start_step >= self.args.max_steps:
+                    return losses
+        return losses
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="CLIP / CLIP+FDT training on MI355X")
+    ap.add_argument("--config", required=True, type=str)
+    ap.add_argument("--output_path", default="./output", type=str)
+    ap.add_argument("--batch_size", default=256, type=int)
+    ap.add_argument("--debug", action="store_true")
+    ap.add_argument("--exp_name", default="", type=str)
+    ap.add_argument("--ckpt_path", default="", type=str)
+    ap.add_argument("--lipreg", default=0, type=float, help="accepted for CLI compatibility with example/clip; must be 0")
+    ap.add_argument("--synthetic", action="store_true", help="train on synthetic pairs resident on the device")
+    ap.add_argument("--max_steps", default=0, type=int, help="stop after this many steps (0 = run the configured epochs)")
+    args = ap.parse_args(argv)
+    if args.lipreg:
+        raise NotImplementedError("--lipreg (Lipschitz regulariser, off by default in the reference) is not on the hot path")
+    if D.get_world_size() > 1:
+        D.init_ddp()
+    else:
+        torch.cuda.set_device(D.get_local_rank())
+        logging.getLogger().setLevel(logging.INFO)
+    solver = ClsSolver(args)
+    solver.train()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,3 +116,22 @@ def test_product_path_refuses_to_run_on_cpu():
     model = model_entry(dict(type="clip_fdt_vitb32", kwargs=model_kwargs(c, FDT_VARIANTS[0])))
     with pytest.raises(RuntimeError):
         model(torch.zeros(2, 3, c["res"], c["res"]), (torch.zeros(2, c["ctx"], dtype=torch.long), torch.zeros(2, c["ctx"])))
+
+
+def test_tokenizer_matches_reference(golden_dir):
+    """ids and pad masks of the reference tokenizer on 16 captions (incl. the >77-token truncation rule
+    [sot] + tok[1:76] + [eot], empty text, punctuation, digits)."""
+    from ilvlm_amd.prototype.model.text_encoder.text_transformer import TextTransformer
+    with open(os.path.join(golden_dir, "g9_tokenizer.json")) as f:
+        g = json.load(f)
+    tt = TextTransformer(embed_dim=8, context_length=77, transformer_width=64, transformer_heads=1, transformer_layers=1,
+                         bpe_path=os.path.join(golden_dir, "bpe_simple_vocab_16e6.txt.gz"))
+    assert len(tt.tokenizer.encoder) == 49409
+    assert tt.tokenizer.encoder["<|startoftext|>"] == 49407 and tt.tokenizer.encoder["<|endoftext|>"] == 49408
+    tok, mask = tt.tokenize(g["captions"])
+    assert tok.tolist() == g["tokens"]
+    assert (mask == 0).int().tolist() == g["pad_mask_valid"]
+    assert torch.all((mask == 0) | torch.isinf(mask))
+    assert tt.tokenizer.decode(tok[0][1:6].tolist()).strip() == "a photo of a cat"
+    wrapped = tt.wrap_tokenize(g["captions"][:2])
+    assert wrapped.out1.shape == (2, 77)
