@@ -1,0 +1,27 @@
+"""Diagnostic: phase cycle breakdown of the pipelined GEMM main loop (needs the -DILVLM_GEMM_STAMPS build)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ilvlm_amd.lib as L
+L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip_stamps.so")
+from ilvlm_amd import ops
+import numpy as np
+M, N, K = 12800, 3072, 768
+a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+for v in (3,):
+    ops.gemm_set_variant(v)
+    for _ in range(3):
+        ops.gemm(a, b, out)
+    torch.cuda.synchronize()
+    nb = min(4096, ((M + 255) // 256) * ((N + 127) // 128))
+    buf = (ctypes.c_ulonglong * (nb * 8 * 6))()
+    rc = L.load().ilvlm_debug_read_stamps(buf, nb * 8 * 6)
+    arr = np.array(buf, dtype=np.float64).reshape(nb, 8, 6)
+    names = ["vmcnt wait", "barrier", "glds issue", "compute", "loop total", "epilogue"]
+    print("variant", v, "blocks", nb, "K-tiles", K // 64)
+    for i, n in enumerate(names):
+        print("  %-12s mean %9.0f  p10 %9.0f  p90 %9.0f cycles/wave" % (n, arr[:, :, i].mean(), np.percentile(arr[:, :, i], 10), np.percentile(arr[:, :, i], 90)))
+    print("  per wave index (mean loop total):", arr[:, :, 4].mean(0).round())
+    print("  per wave index (mean barrier):", arr[:, :, 1].mean(0).round())

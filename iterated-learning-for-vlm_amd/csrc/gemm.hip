@@ -417,6 +417,438 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16* __restr
     }
 }
 
+
+// =====================================================================================
+// bf16 pipelined path ("p8"): 8 waves, BM x BN = 256x128 or 128x256 (each wave a 64x64 sub-tile), BK = 64,
+// THREE direct-to-LDS stages (3 x 48 KiB): the loads of K-tile t+2 are issued while tile t is multiplied, a counted
+// s_waitcnt vmcnt(N) leaves the younger tile in flight, and ONE raw s_barrier per K-tile both publishes tile t and
+// retires the reads of the stage being refilled.  One workgroup per CU (144 KiB LDS), two waves per SIMD.
+// Same swizzled LDS images as the single-buffer kernel (K-contiguous: 128-byte rows; K-strided: BM/BN*2-byte rows).
+// =====================================================================================
+template <bool TR, int ROWS>
+__device__ __forceinline__ void p8_glds(const bf16* __restrict__ src, int ld, int r0, int k0, int R, unsigned char* tile,
+                                        int wave, int lane) {
+    // ROWS x 64 bf16 = ROWS/8 KiB, 8 waves -> ROWS/64 one-KiB segments per wave
+#pragma unroll
+    for (int j = 0; j < ROWS / 64; ++j) {
+        const int seg = wave * (ROWS / 64) + j;
+        const int s = seg * 64 + lane;
+        const bf16* g;
+        if (!TR) {
+            const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
+            g = src + (long)min(r0 + row, R - 1) * ld + k0 + chunk * 8;
+        } else {
+            constexpr int CPR = ROWS / 8;                 // 16-byte chunks per k-row
+            const int kr = s / CPR, slot = s % CPR;
+            const int chunk = (slot & ~15) | ((slot & 15) ^ swz16(kr));
+            g = src + (long)(k0 + kr) * ld + min(r0 + chunk * 8, R - 8);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(tile + seg * 1024), 16, 0, 0);
+    }
+}
+
+template <bool TR, int ROWS>
+__device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, int k32, int lane) {
+    if (!TR) {
+        const int row = r16 + (lane & 15), chunk = (k32 >> 3) + (lane >> 4);
+        return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        constexpr int RB = ROWS * 2;                      // bytes per k-row
+        const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+        const int kr = k32 + 8 * g + q, c = (r16 >> 3) + (p >> 1), half = 8 * (p & 1);
+        const int c_lo = (c & ~15) | ((c & 15) ^ swz16(kr)), c_hi = (c & ~15) | ((c & 15) ^ swz16(kr + 4));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + RB * kr + 16 * c_lo + half));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + RB * (kr + 4) + 16 * c_hi + half));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        return u.v;
+    }
+}
+
+#ifdef ILVLM_GEMM_STAMPS
+// diagnostic build only: per-wave cycle sums of the main-loop phases (never compiled into the product library)
+__device__ unsigned long long g_stamps[4096 * 8 * 6];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(v) unsigned long long v = stamp()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(v)
+#define STAMP_ADD(acc, a, b)
+#endif
+
+template <bool TA, bool TB, bool SWAP, int PBM, int PBN>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                           int ldb, int K, int tiles_m, int tiles_n, int split_k,
+                                                           EpiArgs ep) {
+    constexpr int WN = PBN / 64;                         // waves along N (2 or 4); waves along M = 8 / WN
+    constexpr int A_BYTES = PBM * 128, STAGE = (PBM + PBN) * 128;
+    constexpr int LOADS = (PBM + PBN) / 64;              // global_load_lds per thread per K-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = tiles_m * tiles_n * split_k;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    // order: tn fastest, then the K split, then tm: neighbours share the A panel (and, for split-K, its K slice)
+    const int tn = wg % tiles_n; wg /= tiles_n;
+    const int z = wg % split_k;
+    const int tm = wg / split_k;
+    const int m0 = tm * PBM, n0 = tn * PBN;
+    const int nt_total = K / BK;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0, 0, 0, 0};
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
+    // prologue: tiles t_begin and t_begin+1
+    p8_glds<TA, PBM>(A, lda, m0, t_begin * BK, ep.M, smem_raw, wave, lane);
+    p8_glds<TB, PBN>(B, ldb, n0, t_begin * BK, ep.N, smem_raw + A_BYTES, wave, lane);
+    if (t_begin + 1 < t_end) {
+        p8_glds<TA, PBM>(A, lda, m0, (t_begin + 1) * BK, ep.M, smem_raw + STAGE, wave, lane);
+        p8_glds<TB, PBN>(B, ldb, n0, (t_begin + 1) * BK, ep.N, smem_raw + STAGE + A_BYTES, wave, lane);
+    }
+    int st = 0;   // stage of tile t
+#ifdef ILVLM_GEMM_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+    STAMP(t_start);
+#endif
+    for (int t = t_begin; t < t_end; ++t) {
+        STAMP(s0);
+        if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(s1);
+        __builtin_amdgcn_s_barrier();
+        STAMP(s2_);
+        if (t + 2 < t_end) {
+            const int s2 = st == 0 ? 2 : st - 1;          // (st + 2) % 3
+            p8_glds<TA, PBM>(A, lda, m0, (t + 2) * BK, ep.M, smem_raw + s2 * STAGE, wave, lane);
+            p8_glds<TB, PBN>(B, ldb, n0, (t + 2) * BK, ep.N, smem_raw + s2 * STAGE + A_BYTES, wave, lane);
+        }
+        STAMP(s3);
+        STAMP_ADD(c_wait, s0, s1); STAMP_ADD(c_bar, s1, s2_); STAMP_ADD(c_issue, s2_, s3);
+        const unsigned char* as = smem_raw + st * STAGE;
+        const unsigned char* bs = as + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = p8_frag<TA, PBM>(as, wm * 64 + i * 16, ks * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = p8_frag<TB, PBN>(bs, wn * 64 + j * 16, ks * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            if (rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+#ifdef ILVLM_GEMM_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[3][3]));
+        STAMP(s4);
+        STAMP_ADD(c_comp, s3, s4);
+#endif
+        st = st == 2 ? 0 : st + 1;
+    }
+#ifdef ILVLM_GEMM_STAMPS
+    STAMP(t_loop_end);
+#endif
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (SWAP) {
+                epilogue4<bf16>(ep, m0 + wm * 64 + i * 16 + c, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], alpha);
+            } else {
+                const int n = n0 + wn * 64 + j * 16 + c;
+                if (n < ep.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                        if (m < ep.M)
+                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
+                    }
+                }
+            }
+        }
+        if (rowsum && c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
+            }
+        }
+    }
+#ifdef ILVLM_GEMM_STAMPS
+    STAMP(t_end_);
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 6;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_loop_end - t_start; o[5] = t_end_ - t_loop_end;
+    }
+#endif
+}
+
+
+// =====================================================================================
+// bf16 "dma" path: as the direct-to-LDS kernels above, plus
+//   * operands addressed through buffer descriptors: per-lane byte offsets are computed ONCE, the tile / K-tile offset is
+//     a scalar (soffset), so a load in the main loop is `s_mov m0; buffer_load_dwordx4 .. offen lds` with no VALU, and
+//     rows past the end of the matrix read as zeros (hardware range check) instead of being clamped;
+//   * a two-phase epilogue: every load (bias, residual, saved pre-activation) is issued before the first store, because
+//     vmcnt counts stores too and interleaving them serialises on store latency (in-kernel stamps: epilogue 14.7k cycles
+//     vs 27k for a 12-K-tile main loop before this change);
+//   * static priority for the second half of the waves of an 8-wave workgroup (they lose arbitration otherwise and the
+//     older half idles at the barrier).
+// Tile configs (BM x BN, waves, stages): 128x128 / 4 / 1 (several workgroups per CU), 256x256 / 8 / 2 and
+// 256x128 / 8 / 3 (one workgroup per CU, K-tile t+1 / t+2 in flight during the MFMAs of tile t).
+// =====================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types exist in the device pass only
+template <bool TR, int ROWS, int NTHREADS>
+struct DmaOperand {
+    static constexpr int NLOAD = ROWS * 128 / (NTHREADS * 16);   // loads per thread per K-tile
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[NLOAD];
+    int tile_off;    // byte offset of this workgroup's tile at k = 0
+    int k_step;      // byte offset added per K-tile
+
+    __device__ __forceinline__ void init(const bf16* base, int ld, int r0, int R, int K, int wave, int lane) {
+        const long elems = !TR ? (long)(R - 1) * ld + K : (long)(K - 1) * ld + R;
+        const long bytes = elems * 2;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j) {
+            const int s = (wave * NLOAD + j) * 64 + lane;
+            if (!TR) {
+                const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
+                voff[j] = (row * ld + chunk * 8) * 2;
+            } else {
+                constexpr int CPR = ROWS / 8;
+                const int kr = s / CPR, slot = s % CPR;
+                const int chunk = (slot & ~15) | ((slot & 15) ^ swz16(kr));
+                voff[j] = (kr * ld + chunk * 8) * 2;
+            }
+        }
+        tile_off = !TR ? r0 * ld * 2 : r0 * 2;
+        k_step = !TR ? BK * 2 : BK * ld * 2;
+    }
+    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave) const {
+        const int soff = tile_off + t * k_step;
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
+                                                     16, voff[j], soff, 0, 0);
+    }
+};
+#endif
+
+// fast tile epilogue for SWAP fragments: lane owns row (l&15) and 4 consecutive columns 4*(l>>4).. of each 16x16 tile
+template <int TI, int TJ>
+__device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
+                                              float alpha) {
+    const ilvlm_gemm_epilogue& e = ep.e;
+    const int g = lane >> 4, c = lane & 15;
+    const int npre = (e.residual != nullptr) + (e.rowbias != nullptr) +
+                     (e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD);
+    const bool fast = ep.vec_ok && !e.accumulate && npre <= 1 && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
+    if (!fast) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) epilogue4<bf16>(ep, m_base + i * 16 + c, n_base + j * 16 + 4 * g, acc[i][j], alpha);
+        return;
+    }
+    f32x4 bias[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bias[j] = e.bias ? *(const f32x4*)(e.bias + n_base + j * 16 + 4 * g) : (f32x4){0, 0, 0, 0};
+    const bool bwd = e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD;
+    constexpr int CH = TI <= 4 ? 1 : 2;            // row-tiles per preload batch (register budget: 4 workgroups per CU)
+#pragma unroll
+    for (int i0 = 0; i0 < TI; i0 += CH) {
+        f32x4 pre[CH][TJ];
+        long off[CH];
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            const int m = m_base + (i0 + ii) * 16 + c;
+            off[ii] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n_base + 4 * g;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                if (e.residual) pre[ii][j] = *(const f32x4*)(e.residual + off[ii] + j * 16);
+                else if (e.rowbias) pre[ii][j] = *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * ep.N + n_base + j * 16 + 4 * g);
+                else if (bwd) pre[ii][j] = load4<bf16>((const bf16*)e.aux + off[ii] + j * 16);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                f32x4 v = acc[i0 + ii][j] * alpha + bias[j];
+                if (e.rowbias) v += pre[ii][j];
+                if (e.act == ILVLM_ACT_QUICKGELU || e.act == ILVLM_ACT_GELU_ERF) {
+                    store4<bf16>((bf16*)e.aux + off[ii] + j * 16, v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = e.act == ILVLM_ACT_QUICKGELU ? quick_gelu(v[k]) : gelu_erf(v[k]);
+                } else if (bwd) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[k] *= e.act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(pre[ii][j][k]) : gelu_erf_grad(pre[ii][j][k]);
+                }
+                if (e.residual) v += pre[ii][j];
+                if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[ii] + j * 16, v);
+                else store4<bf16>(ep.Cb + off[ii] + j * 16, v);
+            }
+    }
+}
+
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
+                                                                     const bf16* __restrict__ B, int ldb, int K, int tiles_m,
+                                                                     int tiles_n, int split_k, EpiArgs ep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TI = DBM / WM / 16, TJ = DBN / WN / 16;      // 16x16 tiles per wave
+    constexpr int A_BYTES = DBM * 128, STAGE = (DBM + DBN) * 128;
+    typedef DmaOperand<TA, DBM, NT> OpA;
+    typedef DmaOperand<TB, DBN, NT> OpB;
+    constexpr int LOADS = OpA::NLOAD + OpB::NLOAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = tiles_m * tiles_n * split_k;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int tn = wg % tiles_n; wg /= tiles_n;
+    const int z = wg % split_k;
+    const int tm = wg / split_k;
+    const int m0 = tm * DBM, n0 = tn * DBN;
+    const int nt_total = K / BK;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    OpA opa; OpB opb;
+    opa.init(A, lda, m0, ep.M, K, wave, lane);
+    opb.init(B, ldb, n0, ep.N, K, wave, lane);
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;
+    f32x4 accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) accb[i] = (f32x4){0, 0, 0, 0};
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+    // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+    for (int d = 0; d < NSTAGE - 1; ++d)
+        if (t_begin + d < t_end) {
+            opa.issue(t_begin + d, smem_raw + d * STAGE, wave);
+            opb.issue(t_begin + d, smem_raw + d * STAGE + A_BYTES, wave);
+        }
+    int st = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        if (NSTAGE == 1) {
+            opa.issue(t, smem_raw, wave);
+            opb.issue(t, smem_raw + A_BYTES, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (NSTAGE == 3 && t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int tn_ = t + NSTAGE - 1;
+            if (tn_ < t_end) {
+                const int sn = st == 0 ? NSTAGE - 1 : st - 1;     // (st + NSTAGE - 1) % NSTAGE
+                opa.issue(tn_, smem_raw + sn * STAGE, wave);
+                opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
+            }
+        }
+        const unsigned char* as = smem_raw + st * STAGE;
+        const unsigned char* bs = as + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[TI], fb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM>(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN>(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            if (rowsum) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        if (NSTAGE == 1) __builtin_amdgcn_s_barrier();
+        else st = st == NSTAGE - 1 ? 0 : st + 1;
+    }
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int mw = m0 + wm * (TI * 16), nw = n0 + wn * (TJ * 16);
+    if (SWAP) {
+        epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha);
+    } else {
+        const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int n = nw + j * 16 + c;
+                if (n < ep.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mw + i * 16 + 4 * g + r;
+                        if (m < ep.M)
+                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
+                    }
+                }
+            }
+            if (rowsum && c == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mw + i * 16 + 4 * g + r;
+                    if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
+                }
+            }
+        }
+    }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
 // =====================================================================================
 // fp32 kernel: 64x64x16 tile, 4 waves (2x2), each 32x32 = 2x2 tiles of 16x16x4
 // =====================================================================================
@@ -537,6 +969,38 @@ int launch_glds(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, i
     return ILVLM_OK;
 }
 
+template <bool TA, bool TB, bool SWAP, int PBM, int PBN>
+int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_p8_kernel<TA, TB, SWAP, PBM, PBN>;
+    constexpr int bytes = 3 * (PBM + PBN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_p8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tm = ceil_div(M, PBM), tn = ceil_div(N, PBN);
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_p8");
+    return ILVLM_OK;
+}
+
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE>
+int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE>;
+    constexpr int bytes = NSTAGE * (DBM + DBN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tm = ceil_div(M, DBM), tn = ceil_div(N, DBN);
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(64 * WM * WN), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_dma");
+    return ILVLM_OK;
+}
+
 template <bool TA, bool TB>
 int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
                hipStream_t s) {
@@ -552,7 +1016,7 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 // 0 = register-staged general kernel only, 1 = direct-to-LDS single buffer (default: fastest on the ViT-B/32
 // shapes, benchmarks/gemm_bench.py), 2 = direct-to-LDS double buffer
-int g_gemm_variant = 1;
+int g_gemm_variant = 5;
 
 }  // namespace
 
@@ -599,6 +1063,42 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const int variant = g_gemm_variant;
         const bool fast = variant != 0 && (K % BK == 0) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
+        if (fast && variant >= 5) {
+            // buffer-descriptor DMA kernels: 5 = 128x128 / 4 waves / 1 stage, 6 = 256x256 / 8 waves / 2 stages,
+            // 7 = 256x128 / 8 waves / 3 stages
+#define ILVLM_DMA(TA, TB)                                                                                            \
+    do {                                                                                                             \
+        if (variant == 5)                                                                                            \
+            return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
+                        : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        if (variant == 6)                                                                                            \
+            return swap ? launch_dma<TA, TB, true, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
+                        : launch_dma<TA, TB, false, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
+                    : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
+    } while (0)
+            if (!trans_a && !trans_b) ILVLM_DMA(false, false);
+            if (!trans_a && trans_b) ILVLM_DMA(false, true);
+            if (trans_a && !trans_b) ILVLM_DMA(true, false);
+            ILVLM_DMA(true, true);
+#undef ILVLM_DMA
+        }
+        if (fast && (variant == 3 || variant == 4)) {
+            // pipelined 8-wave kernels: 3 = 256x128 tiles, 4 = 128x256 tiles
+#define ILVLM_P8(TA, TB)                                                                                       \
+    do {                                                                                                       \
+        if (variant == 3)                                                                                      \
+            return swap ? launch_p8<TA, TB, true, 256, 128>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
+                        : launch_p8<TA, TB, false, 256, 128>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
+        return swap ? launch_p8<TA, TB, true, 128, 256>(a, lda, b, ldb, K, M, N, split_k, ep, s)               \
+                    : launch_p8<TA, TB, false, 128, 256>(a, lda, b, ldb, K, M, N, split_k, ep, s);             \
+    } while (0)
+            if (!trans_a && !trans_b) ILVLM_P8(false, false);
+            if (!trans_a && trans_b) ILVLM_P8(false, true);
+            if (trans_a && !trans_b) ILVLM_P8(true, false);
+            ILVLM_P8(true, true);
+#undef ILVLM_P8
+        }
         if (fast) {
 #define ILVLM_FAST(TA, TB)                                                                                   \
     do {                                                                                                     \
@@ -638,7 +1138,14 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant >= 0 && variant <= 2, "gemm_set_variant: 0, 1 or 2");
+    ILVLM_REQUIRE(variant >= 0 && variant <= 7, "gemm_set_variant: 0..7");
     g_gemm_variant = variant;
     return ILVLM_OK;
 }
+
+#ifdef ILVLM_GEMM_STAMPS
+extern "C" int ilvlm_debug_read_stamps(unsigned long long* host_out, int n) {
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+    return (int)e;
+}
+#endif
