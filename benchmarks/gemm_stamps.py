@@ -6,21 +6,24 @@ import ilvlm_amd.lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip_stamps.so")
 from ilvlm_amd import ops
 import numpy as np
-M, N, K = 12800, 3072, 768
-a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
-out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-for v in (3,):
+CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1),
+         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 4)]
+for (tag, ta, tb, M, N, K, acc, split) in CASES:
+    v = 5
+    a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
+    b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else torch.bfloat16)
     ops.gemm_set_variant(v)
     for _ in range(3):
-        ops.gemm(a, b, out)
+        ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split)
     torch.cuda.synchronize()
-    nb = min(4096, ((M + 255) // 256) * ((N + 127) // 128))
+    nb = min(4096, ((M + 127) // 128) * ((N + 127) // 128) * split)
+    print(tag)
     buf = (ctypes.c_ulonglong * (nb * 8 * 6))()
     rc = L.load().ilvlm_debug_read_stamps(buf, nb * 8 * 6)
-    arr = np.array(buf, dtype=np.float64).reshape(nb, 8, 6)
+    arr = np.array(buf, dtype=np.float64).reshape(nb, 8, 6)[:, :4]
     names = ["vmcnt wait", "barrier", "glds issue", "compute", "loop total", "epilogue"]
-    print("variant", v, "blocks", nb, "K-tiles", K // 64)
+    print("variant", v, "blocks", nb, "K-tiles per block", K // 64 // split)
     for i, n in enumerate(names):
         print("  %-12s mean %9.0f  p10 %9.0f  p90 %9.0f cycles/wave" % (n, arr[:, :, i].mean(), np.percentile(arr[:, :, i], 10), np.percentile(arr[:, :, i], 90)))
     print("  per wave index (mean loop total):", arr[:, :, 4].mean(0).round())

@@ -723,7 +723,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
 }
 
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
                                                                      const bf16* __restrict__ B, int ldb, int K, int tiles_m,
                                                                      int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) 
     for (int i = 0; i < TI; ++i) accb[i] = (f32x4){0, 0, 0, 0};
     const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 
-    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (WM * WN == 8 && NSTAGE > 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
@@ -773,21 +773,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) 
             opb.issue(t_begin + d, smem_raw + d * STAGE + A_BYTES, wave);
         }
     int st = 0;
+#ifdef ILVLM_GEMM_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+    STAMP(t_start);
+#endif
     for (int t = t_begin; t < t_end; ++t) {
+#ifdef ILVLM_GEMM_STAMPS
+        unsigned long long q3 = 0;
+#endif
         if (NSTAGE == 1) {
+            STAMP(q0);
             opa.issue(t, smem_raw, wave);
             opb.issue(t, smem_raw + A_BYTES, wave);
+            STAMP(q1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(q2);
             __builtin_amdgcn_s_barrier();
+#ifdef ILVLM_GEMM_STAMPS
+            q3 = stamp();
+#endif
+            STAMP_ADD(c_issue, q0, q1); STAMP_ADD(c_wait, q1, q2); STAMP_ADD(c_bar, q2, q3);
         } else {
             if (NSTAGE == 3 && t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int tn_ = t + NSTAGE - 1;
-            if (tn_ < t_end) {
-                const int sn = st == 0 ? NSTAGE - 1 : st - 1;     // (st + NSTAGE - 1) % NSTAGE
-                opa.issue(tn_, smem_raw + sn * STAGE, wave);
-                opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
+            // NSTAGE == 3: the two waves of a SIMD issue their DMA at opposite ends of the K-tile, so one wave's load
+            // issue (~100 cycles per instruction) overlaps the other's MFMAs instead of both stalling together
+            if (!(NSTAGE == 3 && wave >= 4)) {
+                const int tn_ = t + NSTAGE - 1;
+                if (tn_ < t_end) {
+                    const int sn = st == 0 ? NSTAGE - 1 : st - 1;     // (st + NSTAGE - 1) % NSTAGE
+                    opa.issue(tn_, smem_raw + sn * STAGE, wave);
+                    opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
+                }
             }
         }
         const unsigned char* as = smem_raw + st * STAGE;
@@ -811,10 +829,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) 
                 for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
             }
         }
+#ifdef ILVLM_GEMM_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[TI - 1][TJ - 1]));
+        STAMP(q4);
+#endif
+        if (NSTAGE == 3 && wave >= 4) {
+            const int tn_ = t + 2;
+            if (tn_ < t_end) {
+                const int sn = st == 0 ? 2 : st - 1;
+                opa.issue(tn_, smem_raw + sn * STAGE, wave);
+                opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
+            }
+        }
         if (NSTAGE == 1) __builtin_amdgcn_s_barrier();
         else st = st == NSTAGE - 1 ? 0 : st + 1;
+#ifdef ILVLM_GEMM_STAMPS
+        STAMP(q5);
+        if (NSTAGE == 1) { STAMP_ADD(c_comp, q3, q4); STAMP_ADD(c_bar, q4, q5); }
+#endif
     }
-    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+#ifdef ILVLM_GEMM_STAMPS
+    STAMP(t_loop_end);
+#endif
+    if (WM * WN == 8 && NSTAGE > 1 && wave >= 4) __builtin_amdgcn_s_setprio(0);
 
     float alpha = ep.e.alpha;
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
@@ -846,6 +883,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : 2)) 
             }
         }
     }
+#ifdef ILVLM_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_end_);
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 6;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_loop_end - t_start; o[5] = t_end_ - t_loop_end;
+    }
+#endif
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
@@ -1074,6 +1119,9 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         if (variant == 6)                                                                                            \
             return swap ? launch_dma<TA, TB, true, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
                         : launch_dma<TA, TB, false, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        if (variant == 8)                                                                                            \
+            return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
+                        : launch_dma<TA, TB, false, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
         return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
                     : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
     } while (0)
@@ -1138,7 +1186,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant >= 0 && variant <= 7, "gemm_set_variant: 0..7");
+    ILVLM_REQUIRE(variant >= 0 && variant <= 8, "gemm_set_variant: 0..8");
     g_gemm_variant = variant;
     return ILVLM_OK;
 }

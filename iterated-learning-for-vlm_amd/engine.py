@@ -112,6 +112,19 @@ class Engine:
             raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (self.precision,))
         self.T = torch.bfloat16 if self.precision == "bf16" else torch.float32
         self.arena = None
+        self._side = None
+        self.concurrent_towers = True     # False: everything on the current stream (per-kernel timing, debugging)
+
+    @property
+    def side_stream(self):
+        """Second HIP stream: the text tower runs on it concurrently with the vision tower (independent until the
+        contrastive head), which fills CUs that one tower's launches leave idle.  With concurrent_towers off this is
+        the current stream itself, so the same code path runs serialised."""
+        if not self.concurrent_towers:
+            return torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     # ------------------------------------------------------------------ parameters
     def prepare(self):

@@ -37,28 +37,36 @@ class CLIP(ContrastiveBase):
     def _forward_impl(self, images, tokens, pad_mask, save):
         e = self._eng
         B = images.shape[0]
+        main, side = torch.cuda.current_stream(), e.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):              # text tower concurrently with the vision tower
+            xt, st = e.text_fwd(tokens, save)
+            Lt = tokens.shape[1]
+            txt, _, spt = e.text_pooled(xt, tokens, B, Lt, save)
         xv, sv = e.vision_fwd(images, save)
         Lv = xv.shape[0] // B
         img, _, spv = e.vision_pooled(xv, B, Lv, save)
-        xt, st = e.text_fwd(tokens, save)
-        Lt = tokens.shape[1]
-        txt, _, spt = e.text_pooled(xt, tokens, B, Lt, save)
+        main.wait_stream(side)
         li, lt, sh = e.head_fwd(img, txt, 0.0, 1e-10, save)
         saved = dict(vision=sv, text=st, pv=spv, pt=spt, head=sh, B=B, Lv=Lv, Lt=Lt, xv=xv.shape, xt=xt.shape) if save else None
         return li, lt, saved
 
     def _backward_impl(self, s, dli, dlt):
         e = self._eng
+        main, side = torch.cuda.current_stream(), e.side_stream
         d_img, d_txt = e.head_bwd(s["head"], dli, dlt)
+        d_txt.record_stream(side)
         lp = e.T != torch.float32
-        dxt = torch.zeros(s["xt"], dtype=torch.float32, device=dli.device)
-        e.text_pooled_bwd(s["pt"], d_txt, dxt, s["B"], s["Lt"])
-        dxt_lp = None
-        if lp:
-            dxt_lp = torch.empty(s["xt"], dtype=e.T, device=dli.device)
-            ops.cast_f32(dxt, dxt_lp)
-        e.text_bwd(s["text"], dxt, dxt_lp)
-        self._sync("text_done")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dxt = torch.zeros(s["xt"], dtype=torch.float32, device=dli.device)
+            e.text_pooled_bwd(s["pt"], d_txt, dxt, s["B"], s["Lt"])
+            dxt_lp = None
+            if lp:
+                dxt_lp = torch.empty(s["xt"], dtype=e.T, device=dli.device)
+                ops.cast_f32(dxt, dxt_lp)
+            e.text_bwd(s["text"], dxt, dxt_lp)
+            self._sync("text_done")
         dxv = torch.zeros(s["xv"], dtype=torch.float32, device=dli.device)
         e.vision_pooled_bwd(s["pv"], d_img, dxv, s["B"], s["Lv"])
         dxv_lp = None
@@ -66,6 +74,7 @@ class CLIP(ContrastiveBase):
             dxv_lp = torch.empty(s["xv"], dtype=e.T, device=dli.device)
             ops.cast_f32(dxv, dxv_lp)
         e.vision_bwd(s["vision"], dxv, dxv_lp)
+        main.wait_stream(side)
         self._sync("all_done")
 
     @torch.no_grad()

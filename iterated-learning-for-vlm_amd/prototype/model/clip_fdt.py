@@ -79,33 +79,42 @@ class Clip_FDT(ContrastiveBase):
     def _forward_impl(self, images, tokens, pad_mask, save):
         e = self._eng
         B = images.shape[0]
-        xv, sv = e.vision_fwd(images, save)
+        main, side = torch.cuda.current_stream(), e.side_stream
+        side.wait_stream(main)                     # parameters / shadow / inputs produced on the main stream
+        with torch.cuda.stream(side):              # text tower + text query head
+            xt, st = e.text_fwd(tokens, save)
+            Lt, Wt = tokens.shape[1], xt.shape[1]
+            words, sw = e.text_words(xt, save)
+            qt, sqt = e.qmap_fwd(words, "txt_query_model.", B * Lt, Wt, 0, 0, save)
+            _, ftt, sft = e.fdt_fwd(qt, B, Lt, pad_mask, self.txt_query_model.temperature, save)
+        xv, sv = e.vision_fwd(images, save)        # vision tower + image query head, concurrently on the main stream
         Lv, W = xv.shape[0] // B, xv.shape[1]
-        xt, st = e.text_fwd(tokens, save)
-        Lt, Wt = tokens.shape[1], xt.shape[1]
-        words, sw = e.text_words(xt, save)
         qi, sqi = e.qmap_fwd(xv, "img_query_model.", B * (Lv - 1), W, Lv - 1, 1, save)
         _, fti, sfi = e.fdt_fwd(qi, B, Lv - 1, None, self.img_query_model.temperature, save)
-        qt, sqt = e.qmap_fwd(words, "txt_query_model.", B * Lt, Wt, 0, 0, save)
-        _, ftt, sft = e.fdt_fwd(qt, B, Lt, pad_mask, self.txt_query_model.temperature, save)
+        main.wait_stream(side)
         li, lt, sh = e.head_fwd(fti, ftt, 1e-10, 1e-10, save)
         saved = dict(vision=sv, text=st, words=sw, qi=sqi, fi=sfi, qt=sqt, ft=sft, head=sh, B=B, Lv=Lv, W=W) if save else None
         return li, lt, saved
 
     def _backward_impl(self, s, dli, dlt):
         e = self._eng
+        main, side = torch.cuda.current_stream(), e.side_stream
         d_fti, d_ftt = e.head_bwd(s["head"], dli, dlt)
-        dqt = e.fdt_bwd(s["ft"], d_ftt)
-        dwords = e.qmap_bwd(s["qt"], "txt_query_model.", dqt)
-        dxt, dxt_lp = e.text_words_bwd(s["words"], dwords)
-        e.text_bwd(s["text"], dxt, dxt_lp)
-        dqi = e.fdt_bwd(s["fi"], d_fti)
-        self._sync("text_done")
+        d_ftt.record_stream(side)                  # allocated on the main stream, consumed on the side stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):              # text side
+            dqt = e.fdt_bwd(s["ft"], d_ftt)
+            dwords = e.qmap_bwd(s["qt"], "txt_query_model.", dqt)
+            dxt, dxt_lp = e.text_words_bwd(s["words"], dwords)
+            e.text_bwd(s["text"], dxt, dxt_lp)
+            self._sync("text_done")                # gradient all-reduce of the text ranges waits on this stream
+        dqi = e.fdt_bwd(s["fi"], d_fti)            # image side, concurrently
         B, Lv, W = s["B"], s["Lv"], s["W"]
         dxv = torch.zeros((B * Lv, W), dtype=torch.float32, device=dli.device)
         dxv_lp = torch.zeros((B * Lv, W), dtype=e.T, device=dli.device) if e.T != torch.float32 else None
         e.qmap_bwd(s["qi"], "img_query_model.", dqi, dxv, dxv_lp)
         e.vision_bwd(s["vision"], dxv, dxv_lp)
+        main.wait_stream(side)
         self._sync("all_done")
 
     # ---------------------------------------------------------------- evaluation-time API (no gradient)
