@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 }
 
 // ACT: 0 none, 3 quickgelu', 4 gelu_erf' applied to the low-precision copy only
-template <class TDY, class TX, class TLP>
+template <class TDY, class TX, class TLP, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -64,12 +64,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      float* __restrict__ ws) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 ag[MAXV], ab[MAXV];
+    f32x4 ag[NV], ab[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = (f32x4){0, 0, 0, 0}; }
-    f32x4 gm[MAXV];
+    for (int i = 0; i < NV; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = (f32x4){0, 0, 0, 0}; }
+    f32x4 gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = i * 256 + lane * 4;
         if (c < cols) gm[i] = *(const f32x4*)(gamma + c);
     }
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         const TX* xr = x + srow * (long)cols;
         const TDY* dyr = dy + row * (long)cols;
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[MAXV], gy[MAXV];
+        f32x4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = i * 256 + lane * 4;
             if (c < cols) {
                 f32x4 xv = load4<TX>(xr + c), d = load4<TDY>(dyr + c);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         s1 = wave_sum(s1) / cols;
         s2 = wave_sum(s2) / cols;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = i * 256 + lane * 4;
             if (c < cols) {
                 f32x4 o;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = i * 256 + lane * 4;
             if (i * 256 >= cols) break;   // uniform
             __syncthreads();
@@ -208,9 +208,17 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
     if (blocks > cap) blocks = cap;
     dim3 grid(blocks), block(256);
     const int lp = dx_lp ? dx_lp_dtype : ILVLM_F32;
+    const int nv = (cols + 255) / 256;   // register slots actually needed (1..4): fewer VGPRs -> more waves per SIMD
+#define LN_BWD_NV(TDY, TX, TLP, NV)                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NV>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean, rstd,    \
+                       gamma, dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip, ws)
 #define LN_BWD(TDY, TX, TLP)                                                                                          \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, \
-                       dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip, ws)
+    do {                                                                                                              \
+        if (nv == 1) LN_BWD_NV(TDY, TX, TLP, 1);                                                                      \
+        else if (nv == 2) LN_BWD_NV(TDY, TX, TLP, 2);                                                                 \
+        else if (nv == 3) LN_BWD_NV(TDY, TX, TLP, 3);                                                                 \
+        else LN_BWD_NV(TDY, TX, TLP, 4);                                                                              \
+    } while (0)
     const int key = dy_dtype * 4 + x_dtype * 2 + lp;
     switch (key) {
         case 0: LN_BWD(float, float, float); break;
@@ -224,6 +232,7 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
         default: ILVLM_FAIL(ILVLM_ERR_ARG, "layernorm_bwd: bad dtypes");
     }
 #undef LN_BWD
+#undef LN_BWD_NV
     ILVLM_LAUNCH_CHECK("layernorm_bwd");
     if (ws) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 16), 2), dim3(256), 0, s, ws, blocks, cols, dgamma, dbeta);

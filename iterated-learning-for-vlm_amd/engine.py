@@ -423,8 +423,9 @@ class Engine:
             ops.softmax_fwd(pooled, att_w)
         else:
             raise NotImplementedError("att_func_type=%r has no HIP kernel (supported: sparsemax, softmax)" % cfg["att_func"])
-        att_ft = _empty((B, d), torch.float32, q)
-        ops.gemm(att_w, sd, att_ft, trans_b=True)
+        # [B,C] x [C,d]: only (B/64)*(d/64) output tiles -> split the 4096-deep reduction over 8 workgroups each
+        att_ft = torch.zeros((B, d), dtype=torch.float32, device=q.device)
+        ops.gemm(att_w, sd, att_ft, trans_b=True, accumulate=True, split_k=8 if Cn >= 1024 else 1)
         return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn) if save else None)
 
     def fdt_bwd(self, saved, datt_ft):

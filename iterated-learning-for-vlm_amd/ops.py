@@ -138,7 +138,7 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, group=0, 
             "layernorm_fwd")
 
 
-LN_WS_BLOCKS = 512
+LN_WS_BLOCKS = 1024
 _ln_ws = {}
 
 
