@@ -175,6 +175,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    host_dt = time.perf_counter() - t0          # time the host needed to ENQUEUE the steps (no sync yet)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -230,7 +231,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                        "context_length": 77, "parallelism": "dp%d" % world},
             "step_mfma_frac": round(value / world * FLOPS_PER_PAIR / (PEAK_BF16 * 1e12), 4),
-            "final_loss": round(final_loss, 4),
+            "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(1000.0 * host_dt / args.steps, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

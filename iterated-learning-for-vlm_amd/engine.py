@@ -246,6 +246,7 @@ class Engine:
         for i in reversed(range(cfg["v_layers"])):
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "visual.transformer.resblocks.%d." % i, dx_f32, dx_lp, B, Lv,
                                            cfg["v_heads"], 0)
+            self.m._sync("visual.transformer.resblocks.%d." % i)       # this block's gradients are complete
         dtok = _empty((B * Lv, W), torch.float32, dx_f32)
         ops.layernorm_bwd(dx_f32, saved["tokens"], saved["mean0"], saved["rstd0"], Wf["visual.ln_pre.weight"],
                           Gr["visual.ln_pre.weight"], Gr["visual.ln_pre.bias"], B * Lv, W, dx_f32=dtok)
@@ -309,6 +310,7 @@ class Engine:
         for i in reversed(range(cfg["t_layers"])):
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
                                            Lt, cfg["t_heads"], 1)
+            self.m._sync("encode_text.transformer.resblocks.%d." % i)
         need_tab, need_pos = self.req["encode_text.token_embedding.weight"], self.req["encode_text.positional_embedding"]
         if need_tab:
             ops.embed_bwd(saved["tokens"], dx_f32, Gr["encode_text.token_embedding.weight"],

@@ -53,6 +53,10 @@ def init_ddp(backend="nccl"):
 
 
 class NativeDDP(nn.Module):
+    """Data-parallel wrapper over the flat gradient arena.  The engine announces "<block prefix>" when a transformer
+    block's backward is complete, "text_done" when the text side is finished and "all_done" at the end of backward; each
+    announcement all-reduces (mean) the arena ranges that became final, on a side stream, while backward continues."""
+
     def __init__(self, module):
         super().__init__()
         self.module = module
@@ -61,24 +65,43 @@ class NativeDDP(nn.Module):
         if comm.world()[1] > 1:
             distributed.broadcast(arena.P, 0)      # ONE flattened broadcast (reference: one per state_dict tensor)
         arena.reducer = comm.GradReducer(arena.G)
-        a = arena
-        t0, t1 = a.range_of("encode_text.")
-        q0, q1 = a.range_of("txt_query_model.")
-        self._early = [(t0, t1), (q0, q1)]
-        rest, cur = [], 0
-        for b, e in sorted(self._early):
-            if b > cur:
-                rest.append((cur, b))
-            cur = max(cur, e)
-        if cur < a.total:
-            rest.append((cur, a.total))
-        self._late = rest
+        self._done = []                            # ranges already reduced in this backward
         object.__setattr__(module, "_grad_sync", self._on_sync)
 
+    def _reduce(self, b, e):
+        if e > b:
+            self.module._eng.arena.reducer.reduce_range(b, e)
+            self._done.append((b, e))
+
     def _on_sync(self, what):
-        red = self.module._eng.arena.reducer
-        for b, e in (self._early if what == "text_done" else self._late):
-            red.reduce_range(b, e)
+        a = self.module._eng.arena
+        if what.endswith("."):                     # one transformer block
+            self._reduce(*a.range_of(what))
+        elif what == "text_done":                  # everything of the text side that is not a block
+            t0, t1 = a.range_of("encode_text.")
+            q0, q1 = a.range_of("txt_query_model.")
+            for b, e in self._gaps([(t0, t1), (q0, q1)]):
+                self._reduce(b, e)
+        elif what == "all_done":
+            for b, e in self._gaps([(0, a.total)]):
+                self._reduce(b, e)
+            self._done = []
+
+    def _gaps(self, spans):
+        """parts of `spans` not covered by ranges reduced earlier in this backward"""
+        out = []
+        done = sorted(self._done)
+        for b, e in spans:
+            cur = b
+            for db, de in done:
+                if de <= cur or db >= e:
+                    continue
+                if db > cur:
+                    out.append((cur, db))
+                cur = max(cur, de)
+            if cur < e:
+                out.append((cur, e))
+        return out
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
