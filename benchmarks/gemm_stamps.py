@@ -6,10 +6,9 @@ import ilvlm_amd.lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip_stamps.so")
 from ilvlm_amd import ops
 import numpy as np
-CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1),
-         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 4)]
-for (tag, ta, tb, M, N, K, acc, split) in CASES:
-    v = 5
+CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 5, 128, 128, 4), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 7, 256, 128, 8),
+         ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 6, 256, 256, 8), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 7, 256, 128, 8)]
+for (tag, ta, tb, M, N, K, acc, split, v, bm, bn, nw) in CASES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else torch.bfloat16)
@@ -17,13 +16,13 @@ for (tag, ta, tb, M, N, K, acc, split) in CASES:
     for _ in range(3):
         ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split)
     torch.cuda.synchronize()
-    nb = min(4096, ((M + 127) // 128) * ((N + 127) // 128) * split)
+    nb = min(4096, ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * split)
     print(tag)
     buf = (ctypes.c_ulonglong * (nb * 8 * 6))()
     rc = L.load().ilvlm_debug_read_stamps(buf, nb * 8 * 6)
-    arr = np.array(buf, dtype=np.float64).reshape(nb, 8, 6)[:, :4]
+    arr = np.array(buf, dtype=np.float64).reshape(nb, 8, 6)[:, :nw]
     names = ["vmcnt wait", "barrier", "glds issue", "compute", "loop total", "epilogue"]
-    print("variant", v, "blocks", nb, "K-tiles per block", K // 64 // split)
+    print("variant", v, "tile %dx%d" % (bm, bn), "blocks", nb, "K-tiles per block", K // 64 // split)
     for i, n in enumerate(names):
         print("  %-12s mean %9.0f  p10 %9.0f  p90 %9.0f cycles/wave" % (n, arr[:, :, i].mean(), np.percentile(arr[:, :, i], 10), np.percentile(arr[:, :, i], 90)))
     print("  per wave index (mean loop total):", arr[:, :, 4].mean(0).round())

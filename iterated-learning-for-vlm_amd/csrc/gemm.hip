@@ -448,11 +448,12 @@ __device__ __forceinline__ void p8_glds(const bf16* __restrict__ src, int ld, in
     }
 }
 
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int BKT = 64>
 __device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, int k32, int lane) {
     if (!TR) {
         const int row = r16 + (lane & 15), chunk = (k32 >> 3) + (lane >> 4);
-        return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+        if (BKT == 64) return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+        return *(const bf16x8*)(tile + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
     } else {
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         constexpr int RB = ROWS * 2;                      // bytes per k-row
@@ -626,9 +627,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16* __restric
 // 256x128 / 8 / 3 (one workgroup per CU, K-tile t+1 / t+2 in flight during the MFMAs of tile t).
 // =====================================================================================
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types exist in the device pass only
-template <bool TR, int ROWS, int NTHREADS>
+template <bool TR, int ROWS, int NTHREADS, int BKT>
 struct DmaOperand {
-    static constexpr int NLOAD = ROWS * 128 / (NTHREADS * 16);   // loads per thread per K-tile
+    static constexpr int NLOAD = ROWS * BKT * 2 / (NTHREADS * 16);   // loads per thread per K-tile
     __amdgpu_buffer_rsrc_t rs;
     int voff[NLOAD];
     int tile_off;    // byte offset of this workgroup's tile at k = 0
@@ -642,7 +643,9 @@ struct DmaOperand {
         for (int j = 0; j < NLOAD; ++j) {
             const int s = (wave * NLOAD + j) * 64 + lane;
             if (!TR) {
-                const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
+                // BKT = 64: 128-byte rows, chunk ^ (row & 7); BKT = 32: 64-byte rows, chunk ^ ((row >> 2) & 3)
+                const int row = BKT == 64 ? s >> 3 : s >> 2;
+                const int chunk = BKT == 64 ? (s & 7) ^ (row & 7) : (s & 3) ^ ((row >> 2) & 3);
                 voff[j] = (row * ld + chunk * 8) * 2;
             } else {
                 constexpr int CPR = ROWS / 8;
@@ -652,7 +655,7 @@ struct DmaOperand {
             }
         }
         tile_off = !TR ? r0 * ld * 2 : r0 * 2;
-        k_step = !TR ? BK * 2 : BK * ld * 2;
+        k_step = !TR ? BKT * 2 : BKT * ld * 2;
     }
     __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave) const {
         const int soff = tile_off + t * k_step;
@@ -722,16 +725,16 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
     }
 }
 
-template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE>
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
                                                                      const bf16* __restrict__ B, int ldb, int K, int tiles_m,
                                                                      int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * WM * WN;
     constexpr int TI = DBM / WM / 16, TJ = DBN / WN / 16;      // 16x16 tiles per wave
-    constexpr int A_BYTES = DBM * 128, STAGE = (DBM + DBN) * 128;
-    typedef DmaOperand<TA, DBM, NT> OpA;
-    typedef DmaOperand<TB, DBN, NT> OpB;
+    constexpr int A_BYTES = DBM * BKT * 2, STAGE = (DBM + DBN) * BKT * 2;
+    typedef DmaOperand<TA, DBM, NT, BKT> OpA;
+    typedef DmaOperand<TB, DBN, NT, BKT> OpB;
     constexpr int LOADS = OpA::NLOAD + OpB::NLOAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     const int z = wg % split_k;
     const int tm = wg / split_k;
     const int m0 = tm * DBM, n0 = tn * DBN;
-    const int nt_total = K / BK;
+    const int nt_total = K / BKT;
     const int per = (nt_total + split_k - 1) / split_k;
     const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
     if (t_begin >= t_end) return;
@@ -794,9 +797,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #endif
             STAMP_ADD(c_issue, q0, q1); STAMP_ADD(c_wait, q1, q2); STAMP_ADD(c_bar, q2, q3);
         } else {
+            STAMP(r0);
             if (NSTAGE == 3 && t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(r1);
             __builtin_amdgcn_s_barrier();
+            STAMP(r2);
+            STAMP_ADD(c_wait, r0, r1); STAMP_ADD(c_bar, r1, r2);
             // NSTAGE == 3: the two waves of a SIMD issue their DMA at opposite ends of the K-tile, so one wave's load
             // issue (~100 cycles per instruction) overlaps the other's MFMAs instead of both stalling together
             if (!(NSTAGE == 3 && wave >= 4)) {
@@ -807,16 +814,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
                     opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
                 }
             }
+#ifdef ILVLM_GEMM_STAMPS
+            q3 = stamp();
+            STAMP_ADD(c_issue, r2, q3);
+#endif
         }
         const unsigned char* as = smem_raw + st * STAGE;
         const unsigned char* bs = as + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM>(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+            for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM, BKT>(as, wm * (TI * 16) + i * 16, ks * 32, lane);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN>(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
+            for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN, BKT>(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -846,6 +857,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #ifdef ILVLM_GEMM_STAMPS
         STAMP(q5);
         if (NSTAGE == 1) { STAMP_ADD(c_comp, q3, q4); STAMP_ADD(c_bar, q4, q5); }
+        else { STAMP_ADD(c_comp, q3, q4); STAMP_ADD(c_issue, q4, q5); }
 #endif
     }
 #ifdef ILVLM_GEMM_STAMPS
@@ -1030,10 +1042,10 @@ int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int 
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE>
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT = 64>
 int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE>;
-    constexpr int bytes = NSTAGE * (DBM + DBN) * 128;
+    auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT>;
+    constexpr int bytes = NSTAGE * (DBM + DBN) * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1119,6 +1131,9 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         if (variant == 6)                                                                                            \
             return swap ? launch_dma<TA, TB, true, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
                         : launch_dma<TA, TB, false, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        if (variant == 9)                                                                                            \
+            return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 2, 32>(a, lda, b, ldb, K, M, N, split_k, ep, s)   \
+                        : launch_dma<TA, TB, false, 128, 128, 2, 2, 2, 32>(a, lda, b, ldb, K, M, N, split_k, ep, s); \
         if (variant == 8)                                                                                            \
             return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
                         : launch_dma<TA, TB, false, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
@@ -1186,7 +1201,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant >= 0 && variant <= 8, "gemm_set_variant: 0..8");
+    ILVLM_REQUIRE(variant >= 0 && variant <= 9, "gemm_set_variant: 0..9");
     g_gemm_variant = variant;
     return ILVLM_OK;
 }

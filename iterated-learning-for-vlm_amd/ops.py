@@ -124,10 +124,14 @@ def rowsum_fusable(m, k):
     return k % 64 == 0 and m % 8 == 0 and m >= 8
 
 
+import os as _os
+_WGRAD_TARGET = int(_os.environ.get("ILVLM_WGRAD_TARGET", "384"))
+
+
 def wgrad_split(out_rows, out_cols, k, tile=128):
     """split-K factor for a weight-gradient GEMM: enough workgroups to fill 256 CUs."""
     tiles = math.ceil(out_rows / tile) * math.ceil(out_cols / tile)
-    s = max(1, min(16, round(512 / tiles)))
+    s = max(1, min(16, round(_WGRAD_TARGET / tiles)))
     return max(1, min(s, k // 256 if k >= 256 else 1))
 
 

@@ -29,7 +29,8 @@ def main():
     shutil.copy(stats, os.path.join(a.dst, "kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline",
+    lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --serial-towers",
+             "# (towers serialised so per-kernel durations are those of a kernel owning the chip; the headline run overlaps them)",
              "# GPU busy per train step: %.2f ms  (%d steps)" % (total / a.steps / 1e6, a.steps), "",
              "%7s %9s %10s %10s  %s" % ("share", "calls/st", "avg us", "ms/step", "kernel")]
     for r in rows[:30]:
@@ -58,6 +59,12 @@ def main():
             rd, wr = 2 * fs * 1024 / n / 1e6, ws * 1024 / n / 1e6
             out[k] = dict(read_mb_per_launch=rd, write_mb_per_launch=wr, launches=n)
             lines.append("%-40s %12.2f %12.2f %12d" % (k, rd, wr, n))
+        tot_r = sum(2 * v[0] * 1024 for v in traffic.get("fetch", {}).values())
+        tot_w = sum(v[0] * 1024 for v in traffic.get("write", {}).values())
+        nsteps_pmc = max(1, traffic["fetch"].get("adamw_kernel", [0, 3])[1]) if "fetch" in traffic else 3
+        lines += ["", "# whole step (all kernels): HBM read %.2f GB + write %.2f GB per train step (%d steps in the counter pass)"
+                  % (tot_r / nsteps_pmc / 1e9, tot_w / nsteps_pmc / 1e9, nsteps_pmc)]
+        out["_step_total"] = dict(read_gb=tot_r / nsteps_pmc / 1e9, write_gb=tot_w / nsteps_pmc / 1e9)
         json.dump(out, open(os.path.join(a.dst, "hbm_traffic.json"), "w"), indent=1)
     open(os.path.join(a.dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
