@@ -158,10 +158,10 @@ def main():
         loss = loss / world
         prec1, prec5 = accuracy(li, target, topk=(1, 5))
         opt.zero_grad()
-        model.logit_scale.data.clamp_(min=3, max=6)
+        ops.clamp_(model.logit_scale.data, 3, 6)
         loss.backward()
         opt.step()
-        model.logit_scale.data.clamp_(min=3, max=6)
+        ops.clamp_(model.logit_scale.data, 3, 6)
         return loss
 
     def fence():
@@ -201,8 +201,19 @@ def main():
         s = prof.summary()
         model.engine.concurrent_towers = not args.serial_towers
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch of this kernel family from the committed PMC pass (profiles/round1)
+        try:
+            with open(os.path.join(ROOT, "profiles", "round1", "hbm_traffic.json")) as f:
+                hb = json.load(f)
+            rows = [v for k, v in hb.items() if "gemm_bf16_dma_kernel" in k]
+            n = sum(v["launches"] for v in rows)
+            traffic = round(sum((v["read_mb_per_launch"] + v["write_mb_per_launch"]) * 1e6 * v["launches"] for v in rows) / n)
+        except Exception:
+            pass
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_BF16, 4), traffic=None,
+                        frac=round(achieved / PEAK_BF16, 4), traffic=traffic,
+                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 (gfx950), bytes per launch; "
+                                       "algorithmic bytes per launch ~ 45e6 (profiles/round1/hbm_traffic.json)",
                         kernel="gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step, towers serialised for timing)",
                         launches_per_step=s["launches"] // nprof,
                         gemm_ms_per_step=round(s["ms"] / nprof, 3),

@@ -168,6 +168,12 @@ int ilvlm_colsum(const void* x, int dtype, float* out, long rows, int cols, int 
 int ilvlm_cast_f32(const float* src, void* dst, int dst_dtype, long n, void* stream);
 /* y = a * x (fp32, in place allowed) */
 int ilvlm_scale(const float* x, float* y, float a, long n, void* stream);
+/* y = a[0] * x with the scalar on the device (upstream gradient of the loss, loss.py:46 / train_solver.py:420) */
+int ilvlm_scale_dev(const float* x, float* y, const float* a, long n, void* stream);
+/* y += x (own-slice gradient of the gathered embeddings, clip_fdt.py:182-188) */
+int ilvlm_add_inplace(float* y, const float* x, long n, void* stream);
+/* x = min(max(x, lo), hi) in place (logit_scale.data.clamp_, train_solver.py:381-382, 397-398) */
+int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream);
 
 /* ---- fused multi-tensor AdamW (torch.optim.AdamW semantics, optimizer/__init__.py:3,18-26).
  * The parameters live in one flat fp32 arena; `chunk_*` arrays (device) describe n_chunks pieces:

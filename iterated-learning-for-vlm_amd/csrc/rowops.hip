@@ -317,6 +317,18 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a * x[i];
 }
 
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += x[i];
+}
+__global__ __launch_bounds__(256) void scale_dev_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ a, long n) {
+    const float s = a[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = s * x[i];
+}
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, float lo, float hi, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
 inline int grid_1d(long n, int per_block, int cap = 4096) {
     long g = (n + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -496,5 +508,24 @@ extern "C" int ilvlm_scale(const float* x, float* y, float a, long n, void* stre
     ILVLM_REQUIRE(x && y && n > 0, "scale: bad args");
     hipLaunchKernelGGL(scale_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, S_, x, y, a, n);
     ILVLM_LAUNCH_CHECK("scale");
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_add_inplace(float* y, const float* x, long n, void* stream) {
+    ILVLM_REQUIRE(x && y && n > 0, "add_inplace: bad args");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, S_, y, x, n);
+    ILVLM_LAUNCH_CHECK("add_inplace");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_scale_dev(const float* x, float* y, const float* a, long n, void* stream) {
+    ILVLM_REQUIRE(x && y && a && n > 0, "scale_dev: bad args");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, S_, x, y, a, n);
+    ILVLM_LAUNCH_CHECK("scale_dev");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream) {
+    ILVLM_REQUIRE(x && n > 0 && lo <= hi, "clamp: bad args");
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, S_, x, lo, hi, n);
+    ILVLM_LAUNCH_CHECK("clamp");
     return ILVLM_OK;
 }

@@ -487,8 +487,8 @@ class Engine:
         ops.gemm(dli, img_n, dg_txt, trans_a=True, trans_b=True, alpha_ptr=scale)   # dli^T [Bg,B] . img_n [B,D]
         ops.gemm(dlt, txt_n, dg_img, trans_a=True, trans_b=True, alpha_ptr=scale)
         s_img, s_txt = comm.reduce_gathered(dg_img, dg_txt, B)
-        d_img_n += s_img           # own slice of the gathered-matrix gradient (memory op on [B,D])
-        d_txt_n += s_txt
+        ops.add_inplace(d_img_n, s_img.contiguous())      # own slice of the gathered-matrix gradient
+        ops.add_inplace(d_txt_n, s_txt.contiguous())
         if self.req["logit_scale"]:
             ops.logit_scale_bwd(dli, li, dlt, lt, self.Wf["logit_scale"], scale, self.Gr["logit_scale"])
         d_img = torch.empty_like(img_ft); d_txt = torch.empty_like(txt_ft)

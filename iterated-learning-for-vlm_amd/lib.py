@@ -54,6 +54,9 @@ SIGNATURES = {
     "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
     "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
     "ilvlm_scale": [vp, vp, f32, i64, vp],
+    "ilvlm_scale_dev": [vp, vp, vp, i64, vp],
+    "ilvlm_add_inplace": [vp, vp, i64, vp],
+    "ilvlm_clamp": [vp, f32, f32, i64, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
 }

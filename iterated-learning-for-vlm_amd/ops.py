@@ -321,3 +321,26 @@ def cast_f32(src, dst):
 
 def scale(x, y, a):
     L.check(L.load().ilvlm_scale(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "scale")
+
+
+def scale_dev(x, a_dev, y=None):
+    """y = a_dev[0] * x with a device scalar (fp32)."""
+    _chk(x, "scale_dev.x", torch.float32)
+    y = torch.empty_like(x) if y is None else y
+    a = a_dev.reshape(-1)
+    if a.dtype != torch.float32 or not a.is_cuda or a.numel() != 1:
+        raise RuntimeError("scale_dev: scalar must be a 1-element fp32 device tensor")
+    L.check(L.load().ilvlm_scale_dev(x.data_ptr(), y.data_ptr(), a.data_ptr(), x.numel(), _stream()), "scale_dev")
+    return y
+
+
+def add_inplace(y, x):
+    _chk(y, "add_inplace.y", torch.float32); _chk(x, "add_inplace.x", torch.float32, y.shape)
+    L.check(L.load().ilvlm_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "add_inplace")
+    return y
+
+
+def clamp_(x, lo, hi):
+    _chk(x, "clamp.x", torch.float32)
+    L.check(L.load().ilvlm_clamp(x.data_ptr(), float(lo), float(hi), x.numel(), _stream()), "clamp")
+    return x

@@ -20,8 +20,8 @@ class _InfoNCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         dli, dlt = ctx.saved_tensors
-        g = grad_out.reshape(1, 1)
-        return dli * g, dlt * g, None      # scalar broadcast of the upstream gradient (e.g. 1 / world_size)
+        g = grad_out.reshape(1).to(torch.float32).contiguous()     # device scalar (e.g. 1 / world_size)
+        return ops.scale_dev(dli, g), ops.scale_dev(dlt, g), None
 
 
 class ClipInfoCELoss(_Loss):

@@ -181,10 +181,11 @@ class ClsSolver:
 
     def _clamp_logit_scale(self):
         gc = self.config.grad_clip
+        from . import ops
         if gc.type == "logit_scale_param_value":
-            self.model.module.logit_scale.data.clamp_(min=gc.value, max=gc.max_value)
+            ops.clamp_(self.model.module.logit_scale.data, gc.value, gc.max_value)
         elif gc.type == "logit_scale_param_abs_min":
-            self.model.module.logit_scale.data.clamp_(min=gc.value)
+            ops.clamp_(self.model.module.logit_scale.data, gc.value, float("inf"))
         elif gc.type == "constant":
             self.model.module.logit_scale.requires_grad = False
         else:

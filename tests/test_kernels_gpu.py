@@ -479,3 +479,16 @@ def test_adamw_matches_torch():
     act[sizes[0] + sizes[1]: sizes[0] + sizes[1] + sizes[2]] = False
     assert torch.equal(shadow.cpu()[act], pr.to(torch.bfloat16)[act])
     assert torch.equal(P.cpu()[~act], p0[~act])
+
+
+def test_small_elementwise_kernels():
+    ops = _ops()
+    x, y = rnd(1000, seed=1), rnd(1000, seed=2)
+    Y = dev(y.clone())
+    ops.add_inplace(Y, dev(x))
+    assert rel(Y, x + y) == 0.0
+    a = torch.tensor([0.125], device="cuda")
+    assert rel(ops.scale_dev(dev(x), a), x * 0.125) == 0.0
+    z = dev(torch.tensor([2.0, 3.5, 7.0]))
+    ops.clamp_(z, 3, 6)
+    assert z.cpu().tolist() == [3.0, 3.5, 6.0]
