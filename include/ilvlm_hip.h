@@ -102,7 +102,8 @@ int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype
 /* ---- multi-head self attention core, head_dim 64 (F.multi_head_attention_forward math path reached
  * from base_transformer.py:45-48 / text_encoder/base_transformer.py:45-48; additive causal mask
  * text_transformer.py:147-153).  qkv: T [B*L, 3*64*H] rows = (b, l), columns = [q | k | v] each split
- * into H heads of 64.  out: T [B*L, 64*H].  lse: fp32 [B, H, L] row log-sum-exp saved for backward
+ * into H heads of 64 (bf16: L <= 288; fp32 parity kernels: L <= 96 forward, 80 backward).  out: T [B*L, 64*H].
+ * lse: fp32 [B, H, L] row log-sum-exp saved for backward
  * (the reference materialises the [B*H, L, L] probabilities and their head mean; neither is needed). */
 int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
                         void* stream);
@@ -117,8 +118,9 @@ int ilvlm_embed_bwd(const int64_t* tokens, const float* dx, float* dtable, float
                     int vocab, void* stream);
 
 /* ---- ViT patch embedding helpers (nn.Conv2d k=s=patch as an im2col GEMM, visual_transformer.py:56-63) ----
- * patches[(b*g*g + py*g + px), c*ps*ps + ky*ps + kx] = images[b,c,py*ps+ky,px*ps+kx]  (T out) */
-int ilvlm_patchify(const float* images, void* patches, int dtype, int B, int C, int res, int ps, void* stream);
+ * patches[(b*g*g + py*g + px), c*ps*ps + ky*ps + kx] = images[b,c,py*ps+ky,px*ps+kx]  (T out); rows have stride ld and
+ * columns C*ps*ps .. ld-1 are written as zeros (ViT-L/14: 588 -> 640 so the patch GEMM's K is a multiple of 64) */
+int ilvlm_patchify(const float* images, void* patches, int dtype, int B, int C, int res, int ps, int ld, void* stream);
 /* tokens[b,0,:] = cls + pos[0,:]   (tokens: fp32 [B, L, W]) */
 int ilvlm_cls_rows(const float* cls, const float* pos, float* tokens, int B, int L, int W, void* stream);
 /* out[l,:] += sum_b x[b,l,:] (positional-embedding grad); out0[:] += sum_b x[b,0,:] if out0 (class embedding grad) */

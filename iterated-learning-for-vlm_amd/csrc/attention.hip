@@ -1,5 +1,6 @@
-// Self-attention core for short sequences (L <= 128, head_dim 64): one workgroup per (batch, head), the whole
-// L x L problem resident in LDS.  bf16 path: all five products on v_mfma_f32_16x16x32_bf16, K-strided operands
+// Self-attention core for short sequences (head_dim 64): one workgroup per (batch, head).  L <= 128: the whole
+// L x L problem resident in LDS; 128 < L <= 288 (ViT-B/16 197, ViT-L/14 257 tokens): K/V resident, probabilities per
+// 64-row query round (forward) or per 32-key block (backward).  bf16 path: all five products on v_mfma_f32_16x16x32_bf16, K-strided operands
 // fetched with ds_read_b64_tr_b16 (no transposed copies), fp32 softmax with 16-lane shuffle reductions, only the
 // row log-sum-exp is saved for backward (probabilities are recomputed).  fp32 path: plain VALU kernel used by
 // the fp32 parity mode.
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qk
     bf16* Qs = (bf16*)smem_raw;
     bf16* Ks = Qs + LP * LDH;
     bf16* Vt = Ks + LP * LDH;          // [64][LDP]  (V transposed)
-    bf16* Ps = Vt + HD * LDP;          // [LP][LDP]
+    bf16* Ps = Vt + HD * LDP;          // [64][LDP]: the 4 waves' 16-row slices of the current round
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = HD * H;
@@ -111,12 +112,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qk
                 mx[r] = m; sm[r] = t;
                 const float inv = 1.0f / t;
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) Ps[(qt * 16 + 4 * g + r) * LDP + kt * 16 + c16] = (bf16)(s[kt][r] * inv);
+                for (int kt = 0; kt < NT; ++kt) Ps[(wave * 16 + 4 * g + r) * LDP + kt * 16 + c16] = (bf16)(s[kt][r] * inv);
                 if (c16 == 0 && q < L) lse[((long)b * H + h) * L + q] = m + __logf(t);
             }
             (void)mx; (void)sm;
         }
-        __syncthreads();   // P rows of this round visible (each wave only re-reads its own rows)
+        __syncthreads();   // P rows of this round visible (each wave only re-reads its own 16 rows)
         if (active) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qk
 #pragma unroll
                 for (int ks = 0; ks < LP / 32; ++ks)   // D[d][q] = sum_key Vt[d][key] * P[q][key]
                     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Vt, LDP, dt * 16, ks * 32, lane),
-                                                                frag_k(Ps, LDP, qt * 16, ks * 32, lane), o, 0, 0, 0);
+                                                                frag_k(Ps, LDP, wave * 16, ks * 32, lane), o, 0, 0, 0);
                 const int q = qt * 16 + c16;
                 if (q < L) {
                     bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qk
                 }
             }
         }
+        __syncthreads();   // this round's P slices are consumed before the next round overwrites them
     }
 }
 
@@ -226,6 +228,139 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16* __restrict__ do
             const int coff = which == 2 ? 0 : (which == 1 ? E : 2 * E);
             bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
             *(bf16x4*)(dqkv + ((long)b * L + row) * rs + coff + h * HD + dt * 16 + 4 * g) = ov;
+        }
+    }
+}
+
+
+// Backward for 128 < L <= 288 (ViT-L/14: 257 tokens): the L x L probabilities no longer fit in LDS, so keys are swept in
+// blocks of 32.  Q, dO (whole sequence) stay resident; per key block: P and dS for all query rows (each wave its own
+// 16-row query tiles), dQ accumulated in registers across blocks, dV / dK of the block finished and stored.
+template <int LP>
+__global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
+                                                           const bf16* __restrict__ outp, const float* __restrict__ lse,
+                                                           bf16* __restrict__ dqkv, int L, int H, int causal) {
+    constexpr int NQ = LP / 16, KB = 32, LDB = KB + 8, NA = (NQ + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Qs = (bf16*)smem_raw;            // [LP][72]
+    bf16* dOs = Qs + LP * LDH;             // [LP][72]
+    bf16* Ks = dOs + LP * LDH;             // [32][72]
+    bf16* Vs = Ks + KB * LDH;              // [32][72]
+    bf16* Ps = Vs + KB * LDH;              // [LP][40]
+    bf16* dSs = Ps + LP * LDB;             // [LP][40]
+    float* delta = (float*)(dSs + LP * LDB);
+    float* lses = delta + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
+    const bf16* dob = dout + (long)b * L * E + h * HD;
+    const bf16* ob = outp + (long)b * L * E + h * HD;
+    for (int c = tid; c < LP * 8; c += 256) {
+        int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        float part = 0.f;
+        if (r < L) {
+            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
+            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
+        }
+        *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (ch == 0) delta[r] = part;
+    }
+    for (int r = tid; r < LP; r += 256) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
+
+    const int g = lane >> 4, c16 = lane & 15;
+    f32x4 dq[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dq[a][d] = (f32x4){0, 0, 0, 0};
+
+    for (int kb = 0; kb < LP / KB; ++kb) {
+        {   // this key block's K and V rows: 32 rows x 8 chunks = 256 chunks each, one per thread
+            const int r = tid >> 3, ch = tid & 7, key = kb * KB + r;
+            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key < L) {
+                kv = *(const bf16x8*)(base + E + (long)key * rs + ch * 8);
+                vv = *(const bf16x8*)(base + 2 * E + (long)key * rs + ch * 8);
+            }
+            *(bf16x8*)(Ks + r * LDH + ch * 8) = kv;
+            *(bf16x8*)(Vs + r * LDH + ch * 8) = vv;
+        }
+        __syncthreads();
+        // phase 1: P and dS of this key block for the wave's query tiles
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int qt = wave + 4 * a;
+            if (qt < NQ) {
+                bf16x8 qa0 = frag_k(Qs, LDH, qt * 16, 0, lane), qa1 = frag_k(Qs, LDH, qt * 16, 32, lane);
+                bf16x8 da0 = frag_k(dOs, LDH, qt * 16, 0, lane), da1 = frag_k(dOs, LDH, qt * 16, 32, lane);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(Ks, LDH, kt * 16, 0, lane), sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(Ks, LDH, kt * 16, 32, lane), sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, frag_k(Vs, LDH, kt * 16, 0, lane), dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, frag_k(Vs, LDH, kt * 16, 32, lane), dp, 0, 0, 0);
+                    const int key = kb * KB + kt * 16 + c16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qt * 16 + 4 * g + r;
+                        const bool ok = q < L && key < L && (!causal || key <= q);
+                        const float p = ok ? __expf(sc[r] - lses[q]) : 0.f;
+                        Ps[q * LDB + kt * 16 + c16] = (bf16)p;
+                        dSs[q * LDB + kt * 16 + c16] = (bf16)(p * (dp[r] - delta[q]));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // phase 1b: dQ[q][d] += sum_{key in block} dS[q][key] K[key][d]   (D[d][q], one 32-deep k-step)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int qt = wave + 4 * a;
+            if (qt < NQ) {
+                const bf16x8 dsf = frag_k(dSs, LDB, qt * 16, 0, lane);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    dq[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, LDH, 0, d * 16, lane), dsf, dq[a][d], 0, 0, 0);
+            }
+        }
+        // phase 2: dV / dK of the block: 2 (which) x 2 (key tiles) x 4 (d tiles) output tiles, reduction over all queries
+        for (int job = wave; job < 16; job += 4) {
+            const int which = job >> 3, kt = (job >> 2) & 1, dt = job & 3;
+            const bf16* X = which == 0 ? dOs : Qs;
+            const bf16* Y = which == 0 ? Ps : dSs;
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < LP / 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(X, LDH, ks * 32, dt * 16, lane),
+                                                              frag_tr(Y, LDB, ks * 32, kt * 16, lane), acc, 0, 0, 0);
+            const int key = kb * KB + kt * 16 + c16;
+            if (key < L) {
+                bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
+                *(bf16x4*)(dqkv + ((long)b * L + key) * rs + (which == 0 ? 2 * E : E) + h * HD + dt * 16 + 4 * g) = ov;
+            }
+        }
+        __syncthreads();   // K/V/P/dS of this block are dead: the next block may overwrite them
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int qt = wave + 4 * a, q = qt * 16 + c16;
+        if (qt < NQ && q < L) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 ov = {(bf16)(dq[a][d][0] * 0.125f), (bf16)(dq[a][d][1] * 0.125f), (bf16)(dq[a][d][2] * 0.125f),
+                             (bf16)(dq[a][d][3] * 0.125f)};
+                *(bf16x4*)(dqkv + ((long)b * L + q) * rs + h * HD + d * 16 + 4 * g) = ov;
+            }
         }
     }
 }
@@ -353,7 +488,7 @@ int set_lds(K kern, int bytes, const char* name) {
 template <int LP>
 int launch_fwd_bf16(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, hipStream_t s) {
     constexpr int LDP = LP + 8;
-    constexpr int bytes = (2 * LP * LDH + HD * LDP + LP * LDP) * 2;
+    constexpr int bytes = (2 * LP * LDH + HD * LDP + 64 * LDP) * 2;
     static bool done = false;   // per instantiation; the attribute is idempotent
     if (!done) {
         int rc = set_lds(attn_fwd_bf16<LP>, bytes, "attention_fwd");
@@ -380,6 +515,21 @@ int launch_bwd_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const fl
     return ILVLM_OK;
 }
 
+template <int LP>
+int launch_bwd_tiled_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
+                          int causal, hipStream_t s) {
+    constexpr int bytes = (2 * LP * LDH + 2 * 32 * LDH + 2 * LP * 40) * 2 + 2 * LP * 4;
+    static bool done = false;
+    if (!done) {
+        int rc = set_lds(attn_bwd_tiled_bf16<LP>, bytes, "attention_bwd_tiled");
+        if (rc) return rc;
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_tiled_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_bwd_tiled");
+    return ILVLM_OK;
+}
+
 }  // namespace
 
 extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
@@ -388,13 +538,16 @@ extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int d
     ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_fwd: bad shape B=%d L=%d H=%d", B, L, H);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ILVLM_BF16) {
-        ILVLM_REQUIRE(L <= 128, "attention_fwd(bf16): L=%d > 128 not supported yet", L);
+        ILVLM_REQUIRE(L <= 288, "attention_fwd(bf16): L=%d > 288 not supported", L);
         const bf16* q = (const bf16*)qkv;
         bf16* o = (bf16*)out;
         if (L <= 32) return launch_fwd_bf16<32>(q, o, lse, B, L, H, causal, s);
         if (L <= 64) return launch_fwd_bf16<64>(q, o, lse, B, L, H, causal, s);
         if (L <= 96) return launch_fwd_bf16<96>(q, o, lse, B, L, H, causal, s);
-        return launch_fwd_bf16<128>(q, o, lse, B, L, H, causal, s);
+        if (L <= 128) return launch_fwd_bf16<128>(q, o, lse, B, L, H, causal, s);
+        if (L <= 192) return launch_fwd_bf16<192>(q, o, lse, B, L, H, causal, s);
+        if (L <= 224) return launch_fwd_bf16<224>(q, o, lse, B, L, H, causal, s);
+        return launch_fwd_bf16<288>(q, o, lse, B, L, H, causal, s);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_fwd: bad dtype %d", dtype);
     ILVLM_REQUIRE(L <= 96, "attention_fwd(f32): L=%d > 96 not supported", L);
@@ -416,13 +569,16 @@ extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void
     ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_bwd: bad shape B=%d L=%d H=%d", B, L, H);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ILVLM_BF16) {
-        ILVLM_REQUIRE(L <= 128, "attention_bwd(bf16): L=%d > 128 not supported yet", L);
+        ILVLM_REQUIRE(L <= 288, "attention_bwd(bf16): L=%d > 288 not supported", L);
         const bf16 *d = (const bf16*)dout, *q = (const bf16*)qkv, *o = (const bf16*)out;
         bf16* dq = (bf16*)dqkv;
         if (L <= 32) return launch_bwd_bf16<32>(d, q, o, lse, dq, B, L, H, causal, s);
         if (L <= 64) return launch_bwd_bf16<64>(d, q, o, lse, dq, B, L, H, causal, s);
         if (L <= 96) return launch_bwd_bf16<96>(d, q, o, lse, dq, B, L, H, causal, s);
-        return launch_bwd_bf16<128>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 128) return launch_bwd_bf16<128>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 224) return launch_bwd_tiled_bf16<224>(d, q, o, lse, dq, B, L, H, causal, s);
+        return launch_bwd_tiled_bf16<288>(d, q, o, lse, dq, B, L, H, causal, s);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_bwd: bad dtype %d", dtype);
     ILVLM_REQUIRE(L <= 80, "attention_bwd(f32): L=%d > 80 not supported", L);

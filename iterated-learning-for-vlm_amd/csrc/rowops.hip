@@ -57,16 +57,20 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
 
 template <class T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C,
-                                                       int res, int ps) {
+                                                       int res, int ps, int ld) {
     const int g = res / ps, K = C * ps * ps;
-    const long total = (long)B * g * g * K;
+    const long total = (long)B * g * g * ld;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int k = i % K;
-        long p = i / K;
-        int kx = k % ps, ky = (k / ps) % ps, c = k / (ps * ps);
-        int px = p % g, py = (p / g) % g;
-        long b = p / (g * g);
-        out[i] = from_f<T>(img[((b * C + c) * res + py * ps + ky) * (long)res + px * ps + kx]);
+        int k = i % ld;
+        long p = i / ld;
+        float v = 0.f;                      // columns K..ld-1 are zero padding (K-tile alignment of the patch GEMM)
+        if (k < K) {
+            int kx = k % ps, ky = (k / ps) % ps, c = k / (ps * ps);
+            int px = p % g, py = (p / g) % g;
+            long b = p / (g * g);
+            v = img[((b * C + c) * res + py * ps + ky) * (long)res + px * ps + kx];
+        }
+        out[i] = from_f<T>(v);
     }
 }
 
@@ -368,13 +372,15 @@ extern "C" int ilvlm_cls_rows(const float* cls, const float* pos, float* tokens,
     ILVLM_LAUNCH_CHECK("cls_rows");
     return ILVLM_OK;
 }
-extern "C" int ilvlm_patchify(const float* images, void* patches, int dtype, int B, int C, int res, int ps, void* stream) {
+extern "C" int ilvlm_patchify(const float* images, void* patches, int dtype, int B, int C, int res, int ps, int ld,
+                              void* stream) {
     ILVLM_REQUIRE(images && patches && B > 0 && C > 0 && ps > 0 && res >= ps, "patchify: bad args");
+    ILVLM_REQUIRE(ld >= C * ps * ps, "patchify: ld=%d smaller than the patch length %d", ld, C * ps * ps);
     int g = res / ps;
-    long total = (long)B * g * g * C * ps * ps;
+    long total = (long)B * g * g * ld;
     int grid = grid_1d(total, 256, 8192);
-    if (dtype == ILVLM_BF16) hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(grid), dim3(256), 0, S_, images, (bf16*)patches, B, C, res, ps);
-    else if (dtype == ILVLM_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, S_, images, (float*)patches, B, C, res, ps);
+    if (dtype == ILVLM_BF16) hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(grid), dim3(256), 0, S_, images, (bf16*)patches, B, C, res, ps, ld);
+    else if (dtype == ILVLM_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, S_, images, (float*)patches, B, C, res, ps, ld);
     else ILVLM_FAIL(ILVLM_ERR_ARG, "patchify: bad dtype %d", dtype);
     ILVLM_LAUNCH_CHECK("patchify");
     return ILVLM_OK;

@@ -223,12 +223,19 @@ class Engine:
         g = cfg["res"] // ps
         P, Lv = g * g, g * g + 1
         W = Wf["visual.class_embedding"].shape[0]
-        patches = _empty((B * P, 3 * ps * ps), T, images)
+        K = 3 * ps * ps
+        Kp = (K + 63) // 64 * 64            # patch length padded to the GEMM K-tile (ViT-L/14: 588 -> 640)
+        patches = _empty((B * P, Kp), T, images)
         ops.patchify(images, patches, ps)
+        wconv = self._mat("visual.conv1.weight")
+        if Kp != K:                          # zero-padded copy of the (tiny) patch-embedding matrix; memory op only
+            wpad = torch.zeros((W, Kp), dtype=T, device=images.device)
+            wpad[:, :K].copy_(wconv)
+            wconv = wpad
         tokens = _empty((B * Lv, W), torch.float32, images)
         pos = Wf["visual.positional_embedding"]
         ops.cls_rows(Wf["visual.class_embedding"], pos, tokens, B, Lv, W)
-        ops.gemm(patches, self._mat("visual.conv1.weight"), tokens, rowbias=pos, out_group=P, out_skip=1)
+        ops.gemm(patches, wconv, tokens, rowbias=pos, out_group=P, out_skip=1)
         x = _empty((B * Lv, W), torch.float32, images)
         mean0 = _empty((B * Lv,), torch.float32, images); rstd0 = torch.empty_like(mean0)
         ops.layernorm_fwd(tokens, Wf["visual.ln_pre.weight"], Wf["visual.ln_pre.bias"], x, mean0, rstd0, B * Lv, W)
@@ -256,7 +263,11 @@ class Engine:
             ops.batch_sum(dtok, scratch, Gr["visual.class_embedding"] if need_cls else None, B, Lv, W)
         if self.req["visual.conv1.weight"]:     # frozen by train() in the reference; honoured if someone unfreezes it
             dpatch = dtok.view(B, Lv, W)[:, 1:, :].reshape(B * saved["P"], W).to(self.T).contiguous()
-            self._linear_bwd(dpatch, saved["patches"], "visual.conv1.weight", None, need_dx=False)
+            K = self.Gr["visual.conv1.weight"][0].numel()
+            pt = saved["patches"]
+            if pt.shape[1] != K:             # drop the K padding of the saved patches
+                pt = pt[:, :K].contiguous()
+            self._linear_bwd(dpatch, pt, "visual.conv1.weight", None, need_dx=False)
 
     def vision_pooled(self, x_final, B, Lv, save):
         """ln_post(cls) @ proj -> (projected [B,D] fp32, saved).  Used by the baseline CLIP loss and encode_image."""

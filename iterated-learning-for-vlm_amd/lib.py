@@ -34,7 +34,7 @@ SIGNATURES = {
     "ilvlm_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_embed_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_embed_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "ilvlm_patchify": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "ilvlm_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "ilvlm_cls_rows": [vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_batch_sum": [vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_gather_rows": [vp, vp, vp, i32, i32, i32, vp],

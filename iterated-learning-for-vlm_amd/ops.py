@@ -197,11 +197,13 @@ def embed_bwd(tokens, dx, dtable, dpos):
 def patchify(images, patches, ps):
     B, Cc, res, res2 = images.shape
     g = res // ps
-    _chk(images, "patchify.images", torch.float32); _chk(patches, "patchify.out", None, (B * g * g, Cc * ps * ps))
+    _chk(images, "patchify.images", torch.float32); _chk(patches, "patchify.out")
     if res != res2 or res % ps:
         raise RuntimeError("patchify: bad image size")
-    L.check(L.load().ilvlm_patchify(images.data_ptr(), patches.data_ptr(), dt(patches), B, Cc, res, ps, _stream()),
-            "patchify")
+    if patches.shape[0] != B * g * g or patches.shape[1] < Cc * ps * ps:
+        raise RuntimeError("patchify: output shape %s too small" % (tuple(patches.shape),))
+    L.check(L.load().ilvlm_patchify(images.data_ptr(), patches.data_ptr(), dt(patches), B, Cc, res, ps, patches.shape[1],
+                                    _stream()), "patchify")
 
 
 def cls_rows(cls, pos, tokens, B, Lq, W):

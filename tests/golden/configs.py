@@ -8,6 +8,9 @@ CFG = {
     # non power-of-two everything: 3 heads, 9 patches, 24-token context, 320 codes
     "b": dict(width=192, heads=3, layers=1, res=96, patch=32, embed_dim=64,
               t_width=64, t_heads=1, t_layers=2, ctx=24, sd_num=320, sd_dim=64, batch=3),
+    # ViT-L/14 geometry in small: 14x14 patches (588-long rows, not a multiple of 8), 8x8+1 = 65 tokens, wider text tower
+    "c": dict(width=128, heads=2, layers=1, res=112, patch=14, embed_dim=64,
+              t_width=192, t_heads=3, t_layers=1, ctx=16, sd_num=256, sd_dim=64, batch=3),
 }
 
 FDT_VARIANTS = [

@@ -245,7 +245,8 @@ def attn_ref(qkv, B, L, H, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, 0), (2, 77, 2, 1), (2, 5, 1, 0), (3, 24, 3, 1), (2, 64, 1, 1),
-                                          (2, 10, 1, 0), (1, 100, 2, 0), (1, 128, 1, 1)])
+                                          (2, 10, 1, 0), (1, 100, 2, 0), (1, 128, 1, 1), (2, 257, 2, 0), (1, 197, 1, 0),
+                                          (1, 160, 2, 1), (1, 288, 1, 1)])
 def test_attention(dtype, B, L, H, causal):
     ops = _ops()
     if dtype == torch.float32 and L > 80:
@@ -294,6 +295,12 @@ def test_embedding_and_tokens():
             ops.patchify(dev(img), out, ps)
             want = torch.nn.functional.unfold(img, ps, stride=ps).transpose(1, 2).reshape(-1, 3 * ps * ps)
             assert rel(out, want.to(dtp)) == 0.0
+            kp = (3 * ps * ps + 63) // 64 * 64          # zero-padded rows (K-tile alignment)
+            outp = torch.full((3 * gdim * gdim, kp), 7.0, device="cuda", dtype=dtp)
+            ops.patchify(dev(img), outp, ps)
+            assert rel(outp[:, :3 * ps * ps], want.to(dtp)) == 0.0
+            if kp > 3 * ps * ps:
+                assert float(outp[:, 3 * ps * ps:].abs().max()) == 0.0
     cls, p2 = rnd(W, seed=5), rnd(L, W, seed=6)
     toks = torch.zeros(B * L, W, device="cuda")
     ops.cls_rows(dev(cls), dev(p2), toks, B, L, W)
