@@ -129,11 +129,15 @@ def main():
     from ilvlm_amd.prototype.utils import torch_ddp_dist as D
 
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (one-GPU boxes): ILVLM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, ILVLM_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device).  The driver's real runs use neither.
+    if os.environ.get("ILVLM_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("ILVLM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     D.set_random_seed(0)
     model = model_entry(dict(type="clip_fdt_vitb32", kwargs=vitb32_fdt_kwargs(args.precision)))
