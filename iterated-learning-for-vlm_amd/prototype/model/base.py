@@ -37,7 +37,10 @@ class _StepFn(torch.autograd.Function):
 
 class ContrastiveBase(nn.Module):
     def _init_engine(self, cfg):
+        import weakref
         object.__setattr__(self, "_eng", Engine(self, cfg))
+        for enc in (self.visual, self.encode_text):          # encoders reach the engine for their inference-only calls
+            object.__setattr__(enc, "_owner", weakref.ref(self))
         object.__setattr__(self, "_grad_sync", None)     # set by the data-parallel wrapper
 
     @property

@@ -27,6 +27,28 @@ class VisualTransformer(nn.Module):
         nn.init.normal_(self.positional_embedding, std=0.01)
         init_blocks(self.transformer)
 
+    def forward(self, x, return_dense=False, return_raw_feature=False, return_att=False):
+        """Inference-only call with the reference signature (visual_transformer.py:55-91): projected class feature
+        [, dense patch tokens before ln_post][, ln_post(cls)].  Training goes through the owning model's forward."""
+        if return_att:
+            raise NotImplementedError("attention maps are not produced on the HIP path")
+        owner = getattr(self, "_owner", lambda: None)()
+        if owner is None:
+            raise RuntimeError("VisualTransformer runs inside a CLIP / Clip_FDT model (its engine owns the kernels)")
+        with torch.no_grad():
+            e = owner._eng
+            e.prepare()
+            xv, _ = e.vision_fwd(x, False)
+            B = x.shape[0]
+            Lv = xv.shape[0] // B
+            proj, feat, _ = e.vision_pooled(xv, B, Lv, False)
+        ret = [proj]
+        if return_dense:
+            ret.append(xv.view(B, Lv, -1)[:, 1:, :])
+        if return_raw_feature:
+            ret.append(feat)
+        return ret[0] if len(ret) == 1 else tuple(ret)
+
     def train(self, mode=True):
         super().train(mode)
         if self.freeze_conv1:

@@ -75,6 +75,32 @@ class TextTransformer(nn.Module):
     def wrap_tokenize(self, text):
         return TokenizedOutput(self.tokenize(text))
 
+    def forward(self, text, mask_type=None, return_dense=False, return_raw_feature=False, return_padmask=False,
+                return_att=False, raw_text=True):
+        """Inference-only call with the reference signature (text_transformer.py:211-338): [projected EOT feature,
+        ln_final word features, EOT feature, pad mask] as requested.  Training goes through the owning model."""
+        if mask_type is not None or return_att:
+            raise NotImplementedError("MLM masking / attention maps are not on the HIP path")
+        owner = getattr(self, "_owner", lambda: None)()
+        if owner is None:
+            raise RuntimeError("TextTransformer runs inside a CLIP / Clip_FDT model (its engine owns the kernels)")
+        with torch.no_grad():
+            e = owner._eng
+            e.prepare()
+            tokens, pad_mask = owner._text_inputs(text if raw_text else tuple(text), e.arena.P.device)
+            B, Lt = tokens.shape
+            xt, _ = e.text_fwd(tokens, False)
+            proj, feat, _ = e.text_pooled(xt, tokens, B, Lt, False)
+            ret = [proj]
+            if return_dense:
+                words, _ = e.text_words(xt, False)
+                ret.append(words.view(B, Lt, -1))
+        if return_raw_feature:
+            ret.append(feat)
+        if return_padmask:
+            ret.append(pad_mask)
+        return ret[0] if len(ret) == 1 else ret
+
 
 def text_transformers(**kwargs):
     d = dict(context_length=77, transformer_width=512, transformer_heads=8, transformer_layers=12,

@@ -112,3 +112,35 @@ def test_solver_runs_resets_and_checkpoints(tmp_path):
         assert torch.equal(a.cpu(), b.cpu()), k
     assert sol2.lr_scheduler.last_iter == 10
     sol2.train()
+
+
+def test_eval_zoo_loads_and_averages_checkpoints(tmp_path):
+    """CLIP_benchmark-side consumer: 'module.'-prefixed checkpoints, multi-checkpoint averaging, no-grad encoders."""
+    from ilvlm_amd.eval_zoo import MyModelZoo, average_checkpoints
+    from ilvlm_amd.prototype.utils.misc import EasyDict
+    c = CFG["a"]
+    cfg = EasyDict(model=dict(type="clip_fdt_vitb32", kwargs=dict(model_kwargs(c, FDT_VARIANTS[0]), precision="fp32")))
+    paths = []
+    for i, seed in enumerate((11, 12)):
+        st = {"module." + k: torch.from_numpy(a) for k, a in det_state(state_shapes(c, True), seed).items()}
+        path = tmp_path / ("ckpt_%d.pth.tar" % i)
+        torch.save({"model": st, "optimizer": {}, "last_iter": i}, path)
+        paths.append(str(path))
+    avg = average_checkpoints(paths)
+    want = (det_state(state_shapes(c, True), 11)["space_dict"] + det_state(state_shapes(c, True), 12)["space_dict"]) / 2
+    np.testing.assert_allclose(avg["space_dict"].numpy(), want, rtol=1e-6)
+    zoo = MyModelZoo(cfg, paths)
+    np.testing.assert_allclose(zoo.model.space_dict.detach().cpu().numpy(), want, rtol=1e-6)
+    img = torch.from_numpy(det_images(2, c["res"], 3))
+    tok, mask = det_tokens(2, c["ctx"], 3)
+    ei = zoo.encode_image(img)
+    et = zoo.encode_text((torch.from_numpy(tok), torch.from_numpy(mask)))
+    assert ei.shape == (2, c["sd_dim"]) and et.shape == (2, c["sd_dim"]) and not ei.requires_grad
+    # the encoder containers answer the reference's inference-time calls too (baseline eval path)
+    proj, dense = zoo.model.visual(img.cuda(), return_dense=True)
+    assert proj.shape == (2, c["embed_dim"]) and dense.shape == (2, 4, c["width"])
+    tp, words, feat, pm = zoo.model.encode_text((torch.from_numpy(tok), torch.from_numpy(mask)), return_dense=True,
+                                                return_raw_feature=True, return_padmask=True, raw_text=False)
+    assert tp.shape == (2, c["embed_dim"]) and words.shape == (2, c["ctx"], c["t_width"]) and pm.shape == (2, c["ctx"])
+    single = MyModelZoo(cfg, paths[0])
+    assert torch.equal(single.model.space_dict.detach().cpu(), torch.from_numpy(det_state(state_shapes(c, True), 11)["space_dict"]))
