@@ -15,7 +15,7 @@ SHAPES.append(("fdt.img.scores", 0, 0, 12544, 4096, 512, False, 1))
 SHAPES.append(("fdt.txt.scores", 0, 0, 19712, 4096, 512, False, 1))
 
 
-def run(variants=(5,), rounds=5, only=None):
+def run(variants=(0, 5, 7), rounds=5, only=None):
     torch.manual_seed(0)
     res = {}
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:

@@ -7,7 +7,7 @@ L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip_stamps.so")
 from ilvlm_amd import ops
 import numpy as np
 CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 5, 128, 128, 4), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 7, 256, 128, 8),
-         ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 6, 256, 256, 8), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 7, 256, 128, 8)]
+         ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 5, 128, 128, 4), ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 5, 128, 128, 4)]
 for (tag, ta, tb, M, N, K, acc, split, v, bm, bn, nw) in CASES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)

@@ -78,8 +78,8 @@ typedef struct ilvlm_gemm_epilogue {
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
-/* bf16 kernel selection (tuning / tests): 0 register-staged general kernel, 1 direct-to-LDS single buffer,
- * (default) and 2 direct-to-LDS double buffer.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
+/* bf16 kernel selection (tuning / tests): 0 register-staged general kernel, 5 direct-to-LDS 128x128 (default),
+ * 7 direct-to-LDS 256x128 with a 3-stage ring.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
  * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 

@@ -1,9 +1,9 @@
 // GEMM with fused epilogues for gfx950.
-//   bf16 path : 128x128x64 tile, 4 waves (2x2) each 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles,
-//               double-buffered LDS, next K-tile's global loads in flight during the MFMA phase,
-//               K-contiguous operands read with ds_read_b128, K-strided ("transposed") operands read
-//               with ds_read_b64_tr_b16, so dgrad / wgrad need no transposed copies of weights or
-//               activations.  XCD-aware block remap so one XCD's L2 sees neighbouring tiles.
+//   bf16 path : 128x128x64 tile, 4 waves (2x2) each 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles; operands are DMA'd
+//               into swizzled LDS images (buffer_load_dwordx4 .. lds); K-contiguous operands are read with
+//               ds_read_b128, K-strided ("transposed") ones with ds_read_b64_tr_b16, so dgrad / wgrad need no
+//               transposed copies of weights or activations.  XCD-aware block remap.  A register-staged,
+//               predicated kernel of the same tile takes the shapes the DMA path cannot (K % 64 != 0).
 //   fp32 path : 64x64x16 tile on v_mfma_f32_16x16x4_f32 (bit-exact fp32 FMA chain) for the fp32
 //               parity mode and the small precision-critical products (att@sd, logits).
 // Replaces F.linear / matmul call sites listed in include/ilvlm_hip.h.
@@ -260,193 +260,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
 
 
 // =====================================================================================
-// bf16 fast path: operands DMA'd straight into LDS with global_load_lds_dwordx4 (no VGPR staging).  The LDS images
-// are lane-linear per wave instruction (1 KiB = 64 lanes x 16 B), so the bank-conflict swizzle is applied to the
-// per-lane SOURCE address and undone by the same XOR on the fragment read:
-//   K-contiguous operand : [128 rows][64 k] 128-byte rows, 16-byte chunk c of row r stored at slot c ^ (r & 7)
-//   K-strided operand    : [64 k][128 rows] 256-byte rows, chunk c of k-row r stored at slot c ^ swz(r),
-//                          swz(r) = ((r & 3) << 2) | ((r >> 2) & 3)  (conflict-free for ds_read_b64_tr_b16)
+// LDS images of the direct-to-LDS kernels.  A DMA wave instruction writes 64 lanes x 16 B = 1 KiB linearly, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the fragment read:
+//   K-contiguous operand : [rows][64 k] 128-byte rows, 16-byte chunk c of row r stored at slot c ^ (r & 7)
+//                          ([rows][32 k] 64-byte rows: slot c ^ ((r >> 2) & 3))
+//   K-strided operand    : [k][rows] rows*2-byte rows, chunk c of k-row r stored at slot (c & ~15) | ((c & 15) ^ swz16(r)),
+//                          swz16(r) = ((r & 3) << 2) | ((r >> 2) & 3)  (conflict-free for ds_read_b64_tr_b16)
 // Requirements (checked on the host): K % 64 == 0; a K-strided operand needs rows % 8 == 0.
-// NBUF = 2: tile t+1 is in flight while tile t is multiplied; NBUF = 1: more workgroups per CU instead.
 // =====================================================================================
 __device__ __forceinline__ int swz16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-
-template <bool TR>
-__device__ __forceinline__ void glds_tile(const bf16* __restrict__ src, int ld, int r0, int k0, int R, unsigned char* tile,
-                                          int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int seg = wave * 4 + j;      // 1 KiB segment of the 16 KiB tile
-        const int s = seg * 64 + lane;     // 16-byte slot this lane fills
-        const bf16* g;
-        if (!TR) {
-            const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
-            g = src + (long)min(r0 + row, R - 1) * ld + k0 + chunk * 8;
-        } else {
-            const int kr = s >> 4, chunk = (s & 15) ^ swz16(kr);
-            g = src + (long)(k0 + kr) * ld + min(r0 + chunk * 8, R - 8);
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(tile + seg * 1024), 16, 0, 0);
-    }
-}
-
-template <bool TR>
-__device__ __forceinline__ bf16x8 glds_frag(const unsigned char* tile, int r16, int k32, int lane) {
-    if (!TR) {
-        const int row = r16 + (lane & 15), chunk = (k32 >> 3) + (lane >> 4);
-        return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
-    } else {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
-        const int kr = k32 + 8 * g + q, c = (r16 >> 3) + (p >> 1), half = 8 * (p & 1);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + 256 * kr + 16 * (c ^ swz16(kr)) + half));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(tile + 256 * (kr + 4) + 16 * (c ^ swz16(kr + 4)) + half));
-        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-        u.s.a = lo; u.s.b = hi;
-        return u.v;
-    }
-}
-
-template <bool TA, bool TB, bool SWAP, int NBUF>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                             int ldb, int K, int tiles_m, int tiles_n, int split_k,
-                                                             EpiArgs ep) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = tiles_m * tiles_n * split_k;
-    int wg = xcd_remap(blockIdx.x, nwg);
-    const int z = wg % split_k; wg /= split_k;
-    const int tn = wg % tiles_n, tm = wg / tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nt_total = K / BK;
-    const int per = (nt_total + split_k - 1) / split_k;
-    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
-    if (t_begin >= t_end) return;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0, 0, 0, 0};
-    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-
-    unsigned char* As0 = smem_raw;
-    unsigned char* Bs0 = smem_raw + 16384;
-    glds_tile<TA>(A, lda, m0, t_begin * BK, ep.M, As0, wave, lane);
-    glds_tile<TB>(B, ldb, n0, t_begin * BK, ep.N, Bs0, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        const unsigned char* as = smem_raw + (NBUF == 2 ? cur * 32768 : 0);
-        const unsigned char* bs = as + 16384;
-        if (NBUF == 2 && t + 1 < t_end) {
-            unsigned char* an = smem_raw + (cur ^ 1) * 32768;
-            glds_tile<TA>(A, lda, m0, (t + 1) * BK, ep.M, an, wave, lane);
-            glds_tile<TB>(B, ldb, n0, (t + 1) * BK, ep.N, an + 16384, wave, lane);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = glds_frag<TA>(as, wm * 64 + i * 16, ks * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = glds_frag<TB>(bs, wn * 64 + j * 16, ks * 32, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
-            if (rowsum) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
-            }
-        }
-        if (NBUF == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
-        } else {
-            __syncthreads();
-            if (t + 1 < t_end) {
-                glds_tile<TA>(A, lda, m0, (t + 1) * BK, ep.M, As0, wave, lane);
-                glds_tile<TB>(B, ldb, n0, (t + 1) * BK, ep.N, Bs0, wave, lane);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-    }
-    float alpha = ep.e.alpha;
-    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (SWAP) {
-                epilogue4<bf16>(ep, m0 + wm * 64 + i * 16 + c, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], alpha);
-            } else {
-                const int n = n0 + wn * 64 + j * 16 + c;
-                if (n < ep.N) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
-                        if (m < ep.M)
-                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
-                    }
-                }
-            }
-        }
-        if (rowsum && c == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
-                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
-            }
-        }
-    }
-}
-
-
-// =====================================================================================
-// bf16 pipelined path ("p8"): 8 waves, BM x BN = 256x128 or 128x256 (each wave a 64x64 sub-tile), BK = 64,
-// THREE direct-to-LDS stages (3 x 48 KiB): the loads of K-tile t+2 are issued while tile t is multiplied, a counted
-// s_waitcnt vmcnt(N) leaves the younger tile in flight, and ONE raw s_barrier per K-tile both publishes tile t and
-// retires the reads of the stage being refilled.  One workgroup per CU (144 KiB LDS), two waves per SIMD.
-// Same swizzled LDS images as the single-buffer kernel (K-contiguous: 128-byte rows; K-strided: BM/BN*2-byte rows).
-// =====================================================================================
-template <bool TR, int ROWS>
-__device__ __forceinline__ void p8_glds(const bf16* __restrict__ src, int ld, int r0, int k0, int R, unsigned char* tile,
-                                        int wave, int lane) {
-    // ROWS x 64 bf16 = ROWS/8 KiB, 8 waves -> ROWS/64 one-KiB segments per wave
-#pragma unroll
-    for (int j = 0; j < ROWS / 64; ++j) {
-        const int seg = wave * (ROWS / 64) + j;
-        const int s = seg * 64 + lane;
-        const bf16* g;
-        if (!TR) {
-            const int row = s >> 3, chunk = (s & 7) ^ (row & 7);
-            g = src + (long)min(r0 + row, R - 1) * ld + k0 + chunk * 8;
-        } else {
-            constexpr int CPR = ROWS / 8;                 // 16-byte chunks per k-row
-            const int kr = s / CPR, slot = s % CPR;
-            const int chunk = (slot & ~15) | ((slot & 15) ^ swz16(kr));
-            g = src + (long)(k0 + kr) * ld + min(r0 + chunk * 8, R - 8);
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(tile + seg * 1024), 16, 0, 0);
-    }
-}
 
 template <bool TR, int ROWS, int BKT = 64>
 __device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, int k32, int lane) {
@@ -482,136 +304,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP(v)
 #define STAMP_ADD(acc, a, b)
 #endif
-
-template <bool TA, bool TB, bool SWAP, int PBM, int PBN>
-__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                           int ldb, int K, int tiles_m, int tiles_n, int split_k,
-                                                           EpiArgs ep) {
-    constexpr int WN = PBN / 64;                         // waves along N (2 or 4); waves along M = 8 / WN
-    constexpr int A_BYTES = PBM * 128, STAGE = (PBM + PBN) * 128;
-    constexpr int LOADS = (PBM + PBN) / 64;              // global_load_lds per thread per K-tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int nwg = tiles_m * tiles_n * split_k;
-    int wg = xcd_remap(blockIdx.x, nwg);
-    // order: tn fastest, then the K split, then tm: neighbours share the A panel (and, for split-K, its K slice)
-    const int tn = wg % tiles_n; wg /= tiles_n;
-    const int z = wg % split_k;
-    const int tm = wg / split_k;
-    const int m0 = tm * PBM, n0 = tn * PBN;
-    const int nt_total = K / BK;
-    const int per = (nt_total + split_k - 1) / split_k;
-    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
-    if (t_begin >= t_end) return;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0, 0, 0, 0};
-    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-
-    // prologue: tiles t_begin and t_begin+1
-    p8_glds<TA, PBM>(A, lda, m0, t_begin * BK, ep.M, smem_raw, wave, lane);
-    p8_glds<TB, PBN>(B, ldb, n0, t_begin * BK, ep.N, smem_raw + A_BYTES, wave, lane);
-    if (t_begin + 1 < t_end) {
-        p8_glds<TA, PBM>(A, lda, m0, (t_begin + 1) * BK, ep.M, smem_raw + STAGE, wave, lane);
-        p8_glds<TB, PBN>(B, ldb, n0, (t_begin + 1) * BK, ep.N, smem_raw + STAGE + A_BYTES, wave, lane);
-    }
-    int st = 0;   // stage of tile t
-#ifdef ILVLM_GEMM_STAMPS
-    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
-    STAMP(t_start);
-#endif
-    for (int t = t_begin; t < t_end; ++t) {
-        STAMP(s0);
-        if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(s1);
-        __builtin_amdgcn_s_barrier();
-        STAMP(s2_);
-        if (t + 2 < t_end) {
-            const int s2 = st == 0 ? 2 : st - 1;          // (st + 2) % 3
-            p8_glds<TA, PBM>(A, lda, m0, (t + 2) * BK, ep.M, smem_raw + s2 * STAGE, wave, lane);
-            p8_glds<TB, PBN>(B, ldb, n0, (t + 2) * BK, ep.N, smem_raw + s2 * STAGE + A_BYTES, wave, lane);
-        }
-        STAMP(s3);
-        STAMP_ADD(c_wait, s0, s1); STAMP_ADD(c_bar, s1, s2_); STAMP_ADD(c_issue, s2_, s3);
-        const unsigned char* as = smem_raw + st * STAGE;
-        const unsigned char* bs = as + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = p8_frag<TA, PBM>(as, wm * 64 + i * 16, ks * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = p8_frag<TB, PBN>(bs, wn * 64 + j * 16, ks * 32, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
-            if (rowsum) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
-            }
-        }
-#ifdef ILVLM_GEMM_STAMPS
-        asm volatile("" ::"v"(acc[0][0]), "v"(acc[3][3]));
-        STAMP(s4);
-        STAMP_ADD(c_comp, s3, s4);
-#endif
-        st = st == 2 ? 0 : st + 1;
-    }
-#ifdef ILVLM_GEMM_STAMPS
-    STAMP(t_loop_end);
-#endif
-    float alpha = ep.e.alpha;
-    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (SWAP) {
-                epilogue4<bf16>(ep, m0 + wm * 64 + i * 16 + c, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], alpha);
-            } else {
-                const int n = n0 + wn * 64 + j * 16 + c;
-                if (n < ep.N) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
-                        if (m < ep.M)
-                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
-                    }
-                }
-            }
-        }
-        if (rowsum && c == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
-                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
-            }
-        }
-    }
-#ifdef ILVLM_GEMM_STAMPS
-    STAMP(t_end_);
-    if (lane == 0 && blockIdx.x < 4096) {
-        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 6;
-        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_loop_end - t_start; o[5] = t_end_ - t_loop_end;
-    }
-#endif
-}
-
 
 // =====================================================================================
 // bf16 "dma" path: as the direct-to-LDS kernels above, plus
@@ -1011,37 +703,6 @@ int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, i
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB, bool SWAP, int NBUF>
-int launch_glds(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
-                hipStream_t s) {
-    auto kern = gemm_bf16_glds_kernel<TA, TB, SWAP, NBUF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * 32768);
-        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_glds: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(256), NBUF * 32768, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_glds");
-    return ILVLM_OK;
-}
-
-template <bool TA, bool TB, bool SWAP, int PBM, int PBN>
-int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_p8_kernel<TA, TB, SWAP, PBM, PBN>;
-    constexpr int bytes = 3 * (PBM + PBN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_p8: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const int tm = ceil_div(M, PBM), tn = ceil_div(N, PBN);
-    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_p8");
-    return ILVLM_OK;
-}
-
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT = 64>
 int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
     auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT>;
@@ -1071,8 +732,9 @@ int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, 
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-// 0 = register-staged general kernel only, 1 = direct-to-LDS single buffer (default: fastest on the ViT-B/32
-// shapes, benchmarks/gemm_bench.py), 2 = direct-to-LDS double buffer
+// 0 = register-staged general kernel only; 5 = direct-to-LDS 128x128 single stage (default: fastest on the ViT-B/32
+// shapes, benchmarks/gemm_bench.py); 7 = direct-to-LDS 256x128, 8 waves, 3-stage ring.  (Round-1 exploration also
+// measured global_load_lds addressing, double buffering, 256x256 and BK=32 variants -- all slower; see DESIGN.md.)
 int g_gemm_variant = 5;
 
 }  // namespace
@@ -1120,62 +782,21 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const int variant = g_gemm_variant;
         const bool fast = variant != 0 && (K % BK == 0) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
-        if (fast && variant >= 5) {
-            // buffer-descriptor DMA kernels: 5 = 128x128 / 4 waves / 1 stage, 6 = 256x256 / 8 waves / 2 stages,
-            // 7 = 256x128 / 8 waves / 3 stages
+        if (fast) {
+            // 5 (default) = 128x128 / 4 waves / 1 stage (4 workgroups per CU); 7 = 256x128 / 8 waves / 3-stage ring
 #define ILVLM_DMA(TA, TB)                                                                                            \
     do {                                                                                                             \
-        if (variant == 5)                                                                                            \
-            return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
-                        : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
-        if (variant == 6)                                                                                            \
-            return swap ? launch_dma<TA, TB, true, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
-                        : launch_dma<TA, TB, false, 256, 256, 2, 4, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
-        if (variant == 9)                                                                                            \
-            return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 2, 32>(a, lda, b, ldb, K, M, N, split_k, ep, s)   \
-                        : launch_dma<TA, TB, false, 128, 128, 2, 2, 2, 32>(a, lda, b, ldb, K, M, N, split_k, ep, s); \
-        if (variant == 8)                                                                                            \
-            return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
-                        : launch_dma<TA, TB, false, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
-        return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
-                    : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
+        if (variant == 7)                                                                                            \
+            return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
+                        : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
+                    : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
     } while (0)
             if (!trans_a && !trans_b) ILVLM_DMA(false, false);
             if (!trans_a && trans_b) ILVLM_DMA(false, true);
             if (trans_a && !trans_b) ILVLM_DMA(true, false);
             ILVLM_DMA(true, true);
 #undef ILVLM_DMA
-        }
-        if (fast && (variant == 3 || variant == 4)) {
-            // pipelined 8-wave kernels: 3 = 256x128 tiles, 4 = 128x256 tiles
-#define ILVLM_P8(TA, TB)                                                                                       \
-    do {                                                                                                       \
-        if (variant == 3)                                                                                      \
-            return swap ? launch_p8<TA, TB, true, 256, 128>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
-                        : launch_p8<TA, TB, false, 256, 128>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
-        return swap ? launch_p8<TA, TB, true, 128, 256>(a, lda, b, ldb, K, M, N, split_k, ep, s)               \
-                    : launch_p8<TA, TB, false, 128, 256>(a, lda, b, ldb, K, M, N, split_k, ep, s);             \
-    } while (0)
-            if (!trans_a && !trans_b) ILVLM_P8(false, false);
-            if (!trans_a && trans_b) ILVLM_P8(false, true);
-            if (trans_a && !trans_b) ILVLM_P8(true, false);
-            ILVLM_P8(true, true);
-#undef ILVLM_P8
-        }
-        if (fast) {
-#define ILVLM_FAST(TA, TB)                                                                                   \
-    do {                                                                                                     \
-        if (variant == 1)                                                                                    \
-            return swap ? launch_glds<TA, TB, true, 1>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)            \
-                        : launch_glds<TA, TB, false, 1>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);          \
-        return swap ? launch_glds<TA, TB, true, 2>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)                \
-                    : launch_glds<TA, TB, false, 2>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);              \
-    } while (0)
-            if (!trans_a && !trans_b) ILVLM_FAST(false, false);
-            if (!trans_a && trans_b) ILVLM_FAST(false, true);
-            if (trans_a && !trans_b) ILVLM_FAST(true, false);
-            ILVLM_FAST(true, true);
-#undef ILVLM_FAST
         }
         ILVLM_REQUIRE(epi->a_rowsum == nullptr, "gemm: a_rowsum needs the direct-to-LDS path (K %% 64 == 0, M %% 8 == 0)");
 #define ILVLM_DISPATCH(TA, TB)                                                                       \
@@ -1201,7 +822,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant >= 0 && variant <= 9, "gemm_set_variant: 0..9");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 7, "gemm_set_variant: 0, 5 or 7");
     g_gemm_variant = variant;
     return ILVLM_OK;
 }

@@ -52,12 +52,12 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1
 GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [5, 7])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 392, 256), (136, 2304, 768), (8, 8, 128)])
 def test_gemm_direct_to_lds_variants(variant, ta, tb, M, N, K):
-    """the global_load_lds kernels (single / double buffered), incl. ragged M/N tiles, split-K and the fused
-    bias-gradient row sum"""
+    """the direct-to-LDS kernels (128x128 single stage, 256x128 three-stage ring), incl. ragged M/N tiles, split-K and
+    the fused bias-gradient row sum"""
     ops = _ops()
     a, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2).to(torch.bfloat16)
     want = a.float() @ b.float().t()
