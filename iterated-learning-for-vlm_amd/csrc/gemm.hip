@@ -290,6 +290,11 @@ __device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, in
     }
 }
 
+// ILVLM_GEMM_ABLATE (diagnostic builds only, `make ablate`): 1 = no fragment reads / MFMA, 2 = no operand DMA,
+// 3 = no epilogue -- what each phase of the direct-to-LDS kernel costs with the others left in place
+#ifndef ILVLM_GEMM_ABLATE
+#define ILVLM_GEMM_ABLATE 0
+#endif
 #ifdef ILVLM_GEMM_STAMPS
 // diagnostic build only: per-wave cycle sums of the main-loop phases (never compiled into the product library)
 __device__ unsigned long long g_stamps[4096 * 8 * 6];
@@ -435,8 +440,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     const int nwg = tiles_m * tiles_n * split_k;
     int wg = xcd_remap(blockIdx.x, nwg);
     const int tn = wg % tiles_n; wg /= tiles_n;
-    const int z = wg % split_k;
-    const int tm = wg / split_k;
+    // xcd_remap hands each XCD a contiguous range of wg.  Split-K (weight-gradient) launches order it K-slice major,
+    // so one XCD's L2 sees one K-slice of both operands (each operand row is fetched by ~one XCD instead of all 8);
+    // the other launches keep a tile's K-slices adjacent.
+    int z, tm;
+    if (!SWAP) { tm = wg % tiles_m; z = wg / tiles_m; }
+    else { z = wg % split_k; tm = wg / split_k; }
     const int m0 = tm * DBM, n0 = tn * DBN;
     const int nt_total = K / BKT;
     const int per = (nt_total + split_k - 1) / split_k;
@@ -478,8 +487,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #endif
         if (NSTAGE == 1) {
             STAMP(q0);
+#if ILVLM_GEMM_ABLATE != 2
             opa.issue(t, smem_raw, wave);
             opb.issue(t, smem_raw + A_BYTES, wave);
+#endif
             STAMP(q1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(q2);
@@ -513,6 +524,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
         }
         const unsigned char* as = smem_raw + st * STAGE;
         const unsigned char* bs = as + A_BYTES;
+#if ILVLM_GEMM_ABLATE == 1
+        if (K < 0)
+#endif
 #pragma unroll
         for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 fa[TI], fb[TJ];
@@ -560,6 +574,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     float alpha = ep.e.alpha;
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
     const int mw = m0 + wm * (TI * 16), nw = n0 + wn * (TJ * 16);
+#if ILVLM_GEMM_ABLATE == 3
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     if (SWAP) {
         epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha);
     } else {
