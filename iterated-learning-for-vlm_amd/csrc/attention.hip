@@ -1,9 +1,16 @@
-// Self-attention core for short sequences (head_dim 64): one workgroup per (batch, head).  L <= 128: the whole
-// L x L problem resident in LDS; 128 < L <= 288 (ViT-B/16 197, ViT-L/14 257 tokens): K/V resident, probabilities per
-// 64-row query round (forward) or per 32-key block (backward).  bf16 path: all five products on v_mfma_f32_16x16x32_bf16, K-strided operands
-// fetched with ds_read_b64_tr_b16 (no transposed copies), fp32 softmax with 16-lane shuffle reductions, only the
-// row log-sum-exp is saved for backward (probabilities are recomputed).  fp32 path: plain VALU kernel used by
-// the fp32 parity mode.
+// Self-attention core for short sequences (head_dim 64): one workgroup per (batch, head).
+//   L <= 128 (ViT-B/32: 50, text: 77): one WAVE per 16-row tile.  Forward: the wave owns a 16-query tile, scores are
+//   computed transposed (S^T = K Q^T) so that softmax statistics are in-lane + two cross-lane steps and the
+//   probabilities are already in MFMA B-operand layout for P V -- they never touch LDS; K and V are staged once per
+//   head, Q fragments come straight from global memory.  Backward: pass A (wave = query tile) gives dQ, pass B
+//   (wave = key tile) gives dK and dV with register accumulators, so no cross-wave reduction and one barrier in the
+//   whole kernel; P and dS are recomputed from the saved log-sum-exp in both passes (the MFMAs are not the bottleneck).
+//   41 KB of LDS at L = 77 (was 95 KB): 3 workgroups x 5 waves per CU instead of 1 x 4.
+//   128 < L <= 288 (ViT-B/16 197, ViT-L/14 257 tokens): K/V resident, probabilities per 64-row query round (forward)
+//   or per 32-key block (backward).
+// bf16 path: all products on v_mfma_f32_16x16x32_bf16, K-strided operands fetched with ds_read_b64_tr_b16 (no
+// transposed copies), fp32 softmax, only the row log-sum-exp is saved for backward.  fp32 path: plain VALU kernel used
+// by the fp32 parity mode.
 // Replaces the bmm/baddbmm -> softmax -> bmm sequence of F.multi_head_attention_forward reached from reference
 // image_encoder/base_transformer.py:45-48 and text_encoder/base_transformer.py:45-48 (causal mask
 // text_transformer.py:147-153).  The reference's head-averaged attention weights are discarded by its callers
@@ -30,6 +37,278 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* base, int ld, int k32, int
     union { struct { s16x4 a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
+}
+
+// Same, with a permuted contraction order: the lane's first four values are rows r_lo + 4*(l>>4) + 0..3, the last four
+// rows r_hi + 4*(l>>4) + 0..3 of column c16 + (l&15).  That is the order in which a lane holds two 16x16 MFMA result
+// tiles (rows 4*(l>>4) + r), so a result in registers can be the other operand without a layout change.
+__device__ __forceinline__ bf16x8 frag_tr2(const bf16* base, int ld, int r_lo, int r_hi, int c16, int lane) {
+    int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+    const bf16* a = base + (r_lo + 4 * g + q) * ld + c16 + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + (r_hi - r_lo) * ld));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+__device__ __forceinline__ bf16x8 pack8(bf16x4 a, bf16x4 b) {
+    bf16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return v;
+}
+__device__ __forceinline__ float group4_max(float v) {   // over the four 16-lane groups of a wave (same l & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// [rows < L][64] slice of the packed rows -> [ROWS][72] LDS image, zero padded; NTH threads
+template <int ROWS, int NTH>
+__device__ __forceinline__ void stage_rows(bf16* dst, const bf16* src, long row_stride, int L, float scale, int tid) {
+    for (int c = tid; c < ROWS * 8; c += NTH) {
+        int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < L) {
+            v = *(const bf16x8*)(src + r * row_stride + ch * 8);
+            if (scale != 1.0f)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * scale);
+        }
+        *(bf16x8*)(dst + r * LDH + ch * 8) = v;
+    }
+}
+// one operand fragment straight from global memory: 8 contiguous head-dim values of row `row` (zero beyond L)
+__device__ __forceinline__ bf16x8 frag_global(const bf16* src, long row_stride, int row, int L, int k32, int lane) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < L) v = *(const bf16x8*)(src + row * row_stride + k32 + 8 * (lane >> 4));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L <= 128: one wave per 16-row tile (NT = ceil(L / 16) waves per workgroup)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                         float* __restrict__ lse, int L, int H, int causal) {
+    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Ks = (bf16*)smem_raw;          // [ROWS][72]
+    bf16* Vs = Ks + ROWS * LDH;          // [ROWS][72]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int q = wave * 16 + c16;
+    // the wave's Q tile as B operand (column = query), pre-scaled by 1/sqrt(64) (exact in bf16)
+    bf16x8 qb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qb[ks] = frag_global(base, rs, q, L, ks * 32, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qb[ks][j] = (bf16)((float)qb[ks][j] * 0.125f);
+    }
+    stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
+    stage_rows<ROWS, NTH>(Vs, base + 2 * E, rs, L, 1.0f, tid);
+    __syncthreads();
+
+    const int nkt = causal ? min(NT, wave + 1) : NT;   // key tiles this query tile can see (wave-uniform)
+    f32x4 s[NT];                                       // s[kt][r] = S[q][key = 16 kt + 4 g + r]
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nkt) {
+            f32x4 a = {0, 0, 0, 0};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 0, lane), qb[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 32, lane), qb[1], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                const bool ok = key < L && (!causal || key <= q);
+                a[r] = ok ? a[r] : -INFINITY;
+                m = fmaxf(m, a[r]);
+            }
+            s[kt] = a;
+        }
+    }
+    m = group4_max(m);
+    float t = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - m);
+                s[kt][r] = e;
+                t += e;
+            }
+        }
+    }
+    t = group4_sum(t);
+    const float inv = 1.0f / t;
+    if (g == 0 && q < L) lse[((long)b * H + h) * L + q] = m + __logf(t);
+    bf16x4 pk[NTE];
+#pragma unroll
+    for (int kt = 0; kt < NTE; ++kt) {
+        pk[kt] = (bf16x4){0, 0, 0, 0};
+        if (kt < NT && kt < nkt) pk[kt] = (bf16x4){(bf16)(s[kt][0] * inv), (bf16)(s[kt][1] * inv), (bf16)(s[kt][2] * inv), (bf16)(s[kt][3] * inv)};
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {        // O^T tile: D[d][q] = sum_key V[key][d] P[q][key]
+        f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+        for (int kp = 0; kp < NTE / 2; ++kp)
+            if (2 * kp < nkt)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr2(Vs, LDH, kp * 32, kp * 32 + 16, dt * 16, lane),
+                                                            pack8(pk[2 * kp], pk[2 * kp + 1]), o, 0, 0, 0);
+        if (q < L) {
+            bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+            *(bf16x4*)(out + ((long)b * L + q) * E + h * HD + dt * 16 + 4 * g) = ov;
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
+                                                         const bf16* __restrict__ outp, const float* __restrict__ lse,
+                                                         bf16* __restrict__ dqkv, int L, int H, int causal) {
+    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* Qs = (bf16*)smem_raw;          // [ROWS][72], pre-scaled by 1/8
+    bf16* Ks = Qs + ROWS * LDH;
+    bf16* dOs = Ks + ROWS * LDH;
+    float* delta = (float*)(dOs + ROWS * LDH);   // [ROWS] rowsum(dO * O)
+    float* lses = delta + ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    const bf16* vbase = base + 2 * E;
+    stage_rows<ROWS, NTH>(Qs, base, rs, L, 0.125f, tid);
+    stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
+    const bf16* dob = dout + (long)b * L * E + h * HD;
+    const bf16* ob = outp + (long)b * L * E + h * HD;
+    constexpr int ITER = (ROWS * 8 + NTH - 1) / NTH;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {     // uniform trip count: every lane takes part in the shuffles
+        const int c = tid + it * NTH;
+        const int r = c >> 3, ch = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        float part = 0.f;
+        if (c < ROWS * 8 && r < L) {
+            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
+            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (c < ROWS * 8) {
+            *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
+            if (ch == 0) delta[r] = part;
+        }
+    }
+    for (int r = tid; r < ROWS; r += NTH) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
+    __syncthreads();
+
+    const int g = lane >> 4, c16 = lane & 15;
+    {   // ---- pass A: dQ of query tile `wave`.  Transposed products: lane (g, c16 = q) holds keys 16 kt + 4 g + r.
+        const int q = wave * 16 + c16;
+        const bf16x8 qb0 = frag_k(Qs, LDH, wave * 16, 0, lane), qb1 = frag_k(Qs, LDH, wave * 16, 32, lane);
+        const bf16x8 db0 = frag_k(dOs, LDH, wave * 16, 0, lane), db1 = frag_k(dOs, LDH, wave * 16, 32, lane);
+        const float lq = lses[q], dl = delta[q];
+        const int nkt = causal ? min(NT, wave + 1) : NT;
+        bf16x4 ds[NTE];
+#pragma unroll
+        for (int kt = 0; kt < NTE; ++kt) {
+            ds[kt] = (bf16x4){0, 0, 0, 0};
+            if (kt < NT && kt < nkt) {
+                const int krow = kt * 16 + c16;
+                f32x4 st = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 0, lane), qb0, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 32, lane), qb1, st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_global(vbase, rs, krow, L, 0, lane), db0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_global(vbase, rs, krow, L, 32, lane), db1, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    const bool ok = q < L && key < L && (!causal || key <= q);
+                    const float p = ok ? __expf(st[r] - lq) : 0.f;
+                    ds[kt][r] = (bf16)(p * (dp[r] - dl));
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {    // dQ^T tile: D[d][q] = sum_key K[key][d] dS[q][key]
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int kp = 0; kp < NTE / 2; ++kp)
+                if (2 * kp < nkt)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr2(Ks, LDH, kp * 32, kp * 32 + 16, dt * 16, lane),
+                                                                  pack8(ds[2 * kp], ds[2 * kp + 1]), acc, 0, 0, 0);
+            if (q < L) {
+                bf16x4 ov = {(bf16)(acc[0] * 0.125f), (bf16)(acc[1] * 0.125f), (bf16)(acc[2] * 0.125f), (bf16)(acc[3] * 0.125f)};
+                *(bf16x4*)(dqkv + ((long)b * L + q) * rs + h * HD + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+    {   // ---- pass B: dK, dV of key tile `wave`.  Plain products: lane (g, c16 = key) holds queries 16 qt + 4 g + r.
+        const int key = wave * 16 + c16;
+        const bf16x8 kb0 = frag_k(Ks, LDH, wave * 16, 0, lane), kb1 = frag_k(Ks, LDH, wave * 16, 32, lane);
+        const bf16x8 vb0 = frag_global(vbase, rs, key, L, 0, lane), vb1 = frag_global(vbase, rs, key, L, 32, lane);
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0, 0, 0, 0}; dv[dt] = (f32x4){0, 0, 0, 0}; }
+        const int qt0 = causal ? wave : 0;           // query tiles below the key tile are fully masked
+#pragma unroll
+        for (int kp = 0; kp < NTE / 2; ++kp) {
+            if (2 * kp + 1 >= qt0) {
+                bf16x4 pp[2], pd[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int qt = 2 * kp + hf;
+                    pp[hf] = (bf16x4){0, 0, 0, 0};
+                    pd[hf] = (bf16x4){0, 0, 0, 0};
+                    if (qt < NT && qt >= qt0) {
+                        f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Qs, LDH, qt * 16, 0, lane), kb0, sc, 0, 0, 0);
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Qs, LDH, qt * 16, 32, lane), kb1, sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(dOs, LDH, qt * 16, 0, lane), vb0, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(dOs, LDH, qt * 16, 32, lane), vb1, dp, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qq = qt * 16 + 4 * g + r;
+                            const bool ok = qq < L && key < L && (!causal || key <= qq);
+                            const float p = ok ? __expf(sc[r] - lses[qq]) : 0.f;
+                            pp[hf][r] = (bf16)p;
+                            pd[hf][r] = (bf16)(p * (dp[r] - delta[qq]));
+                        }
+                    }
+                }
+                const bf16x8 bp = pack8(pp[0], pp[1]), bd = pack8(pd[0], pd[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {   // D[d][key] += sum_q X[q][d] Y[q][key]
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr2(dOs, LDH, kp * 32, kp * 32 + 16, dt * 16, lane), bp, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr2(Qs, LDH, kp * 32, kp * 32 + 16, dt * 16, lane), bd, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (key < L) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 kv = {(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                bf16x4 vv = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                bf16* o = dqkv + ((long)b * L + key) * rs + h * HD + dt * 16 + 4 * g;
+                *(bf16x4*)(o + E) = kv;
+                *(bf16x4*)(o + 2 * E) = vv;
+            }
+        }
+    }
 }
 
 // load [L][64] slice (column offset coff of the packed qkv / out rows) into an [LP][72] LDS image, zero padded
@@ -134,101 +413,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qk
             }
         }
         __syncthreads();   // this round's P slices are consumed before the next round overwrites them
-    }
-}
-
-template <int LP>
-__global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
-                                                     const bf16* __restrict__ outp, const float* __restrict__ lse,
-                                                     bf16* __restrict__ dqkv, int L, int H, int causal) {
-    constexpr int NT = LP / 16, LDP = LP + 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* Qs = (bf16*)smem_raw;
-    bf16* Ks = Qs + LP * LDH;
-    bf16* Vs = Ks + LP * LDH;
-    bf16* dOs = Vs + LP * LDH;
-    bf16* Ps = dOs + LP * LDH;         // [LP][LDP]
-    bf16* dSs = Ps + LP * LDP;         // [LP][LDP]
-    float* delta = (float*)(dSs + LP * LDP);
-    float* lses = delta + LP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int E = HD * H;
-    const long rs = 3L * E;
-    const bf16* base = qkv + (long)b * L * rs + h * HD;
-    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
-    load_rows<LP>(Ks, base + E, rs, L, 1.0f, tid);
-    load_rows<LP>(Vs, base + 2 * E, rs, L, 1.0f, tid);
-    const bf16* dob = dout + (long)b * L * E + h * HD;
-    const bf16* ob = outp + (long)b * L * E + h * HD;
-    for (int c = tid; c < LP * 8; c += 256) {   // LP*8 is a multiple of 256: every lane participates in the shuffles
-        int r = c >> 3, ch = c & 7;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        float part = 0.f;
-        if (r < L) {
-            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
-            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
-        }
-        *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        if (ch == 0) delta[r] = part;
-    }
-    for (int r = tid; r < LP; r += 256) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
-    __syncthreads();
-
-    const int g = lane >> 4, c16 = lane & 15;
-    // phase 1: P and dS for every 16-row query tile (all NT tiles so the padded rows are written as zeros)
-    for (int qt = wave; qt < NT; qt += 4) {
-        bf16x8 qa0 = frag_k(Qs, LDH, qt * 16, 0, lane), qa1 = frag_k(Qs, LDH, qt * 16, 32, lane);
-        bf16x8 da0 = frag_k(dOs, LDH, qt * 16, 0, lane), da1 = frag_k(dOs, LDH, qt * 16, 32, lane);
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(Ks, LDH, kt * 16, 0, lane), s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(Ks, LDH, kt * 16, 32, lane), s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, frag_k(Vs, LDH, kt * 16, 0, lane), dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, frag_k(Vs, LDH, kt * 16, 32, lane), dp, 0, 0, 0);
-            const int key = kt * 16 + c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qt * 16 + 4 * g + r;
-                const bool ok = q < L && key < L && (!causal || key <= q);
-                float p = ok ? __expf(s[r] - lses[q]) : 0.f;
-                float ds = p * (dp[r] - delta[q]);
-                Ps[q * LDP + key] = (bf16)p;
-                dSs[q * LDP + key] = (bf16)ds;
-            }
-        }
-    }
-    __syncthreads();
-    // phase 2: dV = P^T dO, dK = dS^T (Q/8), dQ = (dS K)/8 ; 3 * NT * 4 independent 16x16 output tiles
-    for (int job = wave; job < 3 * NT * 4; job += 4) {
-        const int which = job / (NT * 4), rt = (job >> 2) % NT, dt = job & 3;
-        f32x4 acc = {0, 0, 0, 0};
-        if (which == 2) {          // dQ[q][d]: D[d][q] = sum_key K[key][d] * dS[q][key]
-#pragma unroll
-            for (int ks = 0; ks < LP / 32; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, LDH, ks * 32, dt * 16, lane),
-                                                              frag_k(dSs, LDP, rt * 16, ks * 32, lane), acc, 0, 0, 0);
-            acc *= 0.125f;
-        } else {                   // dV / dK [key][d]: D[d][key] = sum_q X[q][d] * Y[q][key]
-            const bf16* X = which == 0 ? dOs : Qs;
-            const bf16* Y = which == 0 ? Ps : dSs;
-#pragma unroll
-            for (int ks = 0; ks < LP / 32; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(X, LDH, ks * 32, dt * 16, lane),
-                                                              frag_tr(Y, LDP, ks * 32, rt * 16, lane), acc, 0, 0, 0);
-        }
-        const int row = rt * 16 + c16;
-        if (row < L) {
-            const int coff = which == 2 ? 0 : (which == 1 ? E : 2 * E);
-            bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
-            *(bf16x4*)(dqkv + ((long)b * L + row) * rs + coff + h * HD + dt * 16 + 4 * g) = ov;
-        }
     }
 }
 
@@ -499,18 +683,20 @@ int launch_fwd_bf16(const bf16* qkv, bf16* out, float* lse, int B, int L, int H,
     ILVLM_LAUNCH_CHECK("attention_fwd");
     return ILVLM_OK;
 }
-template <int LP>
-int launch_bwd_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
+template <int NT>
+int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, hipStream_t s) {
+    constexpr int ROWS = ((NT + 1) & ~1) * 16;
+    constexpr int bytes = 2 * ROWS * LDH * 2;
+    hipLaunchKernelGGL((attn_fwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, qkv, out, lse, L, H, causal);
+    ILVLM_LAUNCH_CHECK("attention_fwd");
+    return ILVLM_OK;
+}
+template <int NT>
+int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
                     int causal, hipStream_t s) {
-    constexpr int LDP = LP + 8;
-    constexpr int bytes = (4 * LP * LDH + 2 * LP * LDP) * 2 + 2 * LP * 4;
-    static bool done = false;
-    if (!done) {
-        int rc = set_lds(attn_bwd_bf16<LP>, bytes, "attention_bwd");
-        if (rc) return rc;
-        done = true;
-    }
-    hipLaunchKernelGGL((attn_bwd_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
+    constexpr int ROWS = ((NT + 1) & ~1) * 16;
+    constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // <= 57 KB: below the 64 KB default limit
+    hipLaunchKernelGGL((attn_bwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
     ILVLM_LAUNCH_CHECK("attention_bwd");
     return ILVLM_OK;
 }
@@ -541,10 +727,17 @@ extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int d
         ILVLM_REQUIRE(L <= 288, "attention_fwd(bf16): L=%d > 288 not supported", L);
         const bf16* q = (const bf16*)qkv;
         bf16* o = (bf16*)out;
-        if (L <= 32) return launch_fwd_bf16<32>(q, o, lse, B, L, H, causal, s);
-        if (L <= 64) return launch_fwd_bf16<64>(q, o, lse, B, L, H, causal, s);
-        if (L <= 96) return launch_fwd_bf16<96>(q, o, lse, B, L, H, causal, s);
-        if (L <= 128) return launch_fwd_bf16<128>(q, o, lse, B, L, H, causal, s);
+        switch ((L + 15) / 16) {
+            case 1: return launch_fwd_wave<1>(q, o, lse, B, L, H, causal, s);
+            case 2: return launch_fwd_wave<2>(q, o, lse, B, L, H, causal, s);
+            case 3: return launch_fwd_wave<3>(q, o, lse, B, L, H, causal, s);
+            case 4: return launch_fwd_wave<4>(q, o, lse, B, L, H, causal, s);
+            case 5: return launch_fwd_wave<5>(q, o, lse, B, L, H, causal, s);
+            case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, s);
+            case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, s);
+            case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, s);
+            default: break;
+        }
         if (L <= 192) return launch_fwd_bf16<192>(q, o, lse, B, L, H, causal, s);
         if (L <= 224) return launch_fwd_bf16<224>(q, o, lse, B, L, H, causal, s);
         return launch_fwd_bf16<288>(q, o, lse, B, L, H, causal, s);
@@ -572,10 +765,17 @@ extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void
         ILVLM_REQUIRE(L <= 288, "attention_bwd(bf16): L=%d > 288 not supported", L);
         const bf16 *d = (const bf16*)dout, *q = (const bf16*)qkv, *o = (const bf16*)out;
         bf16* dq = (bf16*)dqkv;
-        if (L <= 32) return launch_bwd_bf16<32>(d, q, o, lse, dq, B, L, H, causal, s);
-        if (L <= 64) return launch_bwd_bf16<64>(d, q, o, lse, dq, B, L, H, causal, s);
-        if (L <= 96) return launch_bwd_bf16<96>(d, q, o, lse, dq, B, L, H, causal, s);
-        if (L <= 128) return launch_bwd_bf16<128>(d, q, o, lse, dq, B, L, H, causal, s);
+        switch ((L + 15) / 16) {
+            case 1: return launch_bwd_wave<1>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 2: return launch_bwd_wave<2>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 3: return launch_bwd_wave<3>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 4: return launch_bwd_wave<4>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 5: return launch_bwd_wave<5>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, s);
+            case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, s);
+            default: break;
+        }
         if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s);
         if (L <= 224) return launch_bwd_tiled_bf16<224>(d, q, o, lse, dq, B, L, H, causal, s);
         return launch_bwd_tiled_bf16<288>(d, q, o, lse, dq, B, L, H, causal, s);

@@ -246,7 +246,8 @@ def attn_ref(qkv, B, L, H, causal):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, 0), (2, 77, 2, 1), (2, 5, 1, 0), (3, 24, 3, 1), (2, 64, 1, 1),
                                           (2, 10, 1, 0), (1, 100, 2, 0), (1, 128, 1, 1), (2, 257, 2, 0), (1, 197, 1, 0),
-                                          (1, 160, 2, 1), (1, 288, 1, 1)])
+                                          (1, 160, 2, 1), (1, 288, 1, 1), (1, 16, 1, 1), (2, 17, 2, 0), (1, 33, 1, 1),
+                                          (1, 96, 2, 0), (1, 112, 1, 1), (2, 80, 2, 1), (1, 1, 1, 0), (1, 129, 1, 1)])
 def test_attention(dtype, B, L, H, causal):
     ops = _ops()
     if dtype == torch.float32 and L > 80:
