@@ -193,6 +193,21 @@ int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* e
                      const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
                      int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream);
 
+/* ---- host-side byte-level BPE tokenizer (no GPU work).  Replaces SimpleTokenizer.encode / bpe
+ * (prototype/model/utils/text_utils/simple_tokenizer.py:63-135) and TextTransformer.tokenize framing
+ * (text_encoder/text_transformer.py:155-202) that the reference runs in Python inside every forward().
+ * create: `merges_text` is the DECOMPRESSED bpe_simple_vocab_16e6.txt (header line + one merge per line); the
+ *         handle is thread-safe (calls serialise on an internal mutex) and owns no device memory.
+ * encode: texts[n] NUL-terminated UTF-8 -> tokens[n][ctx] (int64: <|startoftext|> ids <|endoftext|> 0...; over-long
+ *         captions keep sot + the first ctx-2 ids + eot), pad_mask[n][ctx] (0 valid / -inf pad), lengths[n].
+ *         Captions with bytes outside printable ASCII / ASCII white space, or with '&' (HTML entities), need the
+ *         reference's Unicode cleaning: they are reported in fallback[i] = 1 with their rows untouched, for the caller's
+ *         full-Unicode tokenizer. */
+int ilvlm_tokenizer_create(const char* merges_text, long nbytes, void** handle);
+int ilvlm_tokenizer_encode(void* handle, const char* const* texts, int n, int context_length, long long* tokens,
+                           float* pad_mask, int* lengths, unsigned char* fallback);
+int ilvlm_tokenizer_destroy(void* handle);
+
 /* ---- self tests of the MFMA / LDS-transpose fragment maps (used by tests only) ---- */
 int ilvlm_selftest_fragments(float* out /* [5][64][8] */, void* stream);
 

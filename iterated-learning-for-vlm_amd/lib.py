@@ -59,6 +59,9 @@ SIGNATURES = {
     "ilvlm_clamp": [vp, f32, f32, i64, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
+    "ilvlm_tokenizer_create": [C.c_char_p, i64, C.POINTER(vp)],
+    "ilvlm_tokenizer_encode": [vp, C.POINTER(C.c_char_p), i32, i32, vp, vp, vp, vp],
+    "ilvlm_tokenizer_destroy": [vp],
 }
 
 _lib = None

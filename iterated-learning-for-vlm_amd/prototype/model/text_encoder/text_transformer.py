@@ -50,6 +50,13 @@ class TextTransformer(nn.Module):
             self._tokenizer = SimpleTokenizer(self.bpe_path)
         return self._tokenizer
 
+    @property
+    def native_tokenizer(self):
+        if getattr(self, "_native_tokenizer", None) is None:
+            from ..utils.text_utils.simple_tokenizer import NativeTokenizer
+            self._native_tokenizer = NativeTokenizer(self.tokenizer)
+        return self._native_tokenizer
+
     def tokenize(self, texts, context_length=None, return_length=False, mask_type=None):
         """list[str] -> (tokens int64 [B,ctx], pad_mask fp32 [B,ctx] with 0 valid / -inf pad); over-long captions keep
         [sot] + tok[1:ctx-1] + [eot] (reference text_transformer.py:155-202)."""
@@ -58,16 +65,8 @@ class TextTransformer(nn.Module):
         ctx = context_length or self.context_length
         if isinstance(texts, str):
             texts = [texts]
-        rows = [[SOT] + self.tokenizer.encode(t) + [EOT] for t in texts]
-        result = torch.zeros(len(rows), ctx, dtype=torch.long)
-        pad_mask = torch.full((len(rows), ctx), float("-inf"))
-        lengths = torch.ones(len(rows), dtype=torch.long)
-        for i, toks in enumerate(rows):
-            if len(toks) > ctx:
-                toks = [toks[0]] + toks[1:ctx - 1] + [toks[-1]]
-            result[i, :len(toks)] = torch.tensor(toks, dtype=torch.long)
-            pad_mask[i, :len(toks)] = 0
-            lengths[i] = len(toks)
+        # C++ BPE (ilvlm_tokenizer_*): the reference runs this loop in Python inside every forward()
+        result, pad_mask, lengths = self.native_tokenizer.encode_batch(list(texts), ctx, SOT, EOT)
         if return_length:
             return result, lengths, pad_mask
         return result, pad_mask

@@ -40,7 +40,8 @@ class SimpleTokenizer(object):
                                     "or feed pre-tokenised (tokens, pad_mask) pairs to the model" % (bpe_path,))
         self.byte_encoder = byte_symbols()
         self.byte_decoder = {c: b for b, c in self.byte_encoder.items()}
-        lines = gzip.open(bpe_path).read().decode("utf-8").split("\n")
+        self._vocab_text = gzip.open(bpe_path).read()
+        lines = self._vocab_text.decode("utf-8").split("\n")
         merges = [tuple(l.split()) for l in lines[1:N_MERGES + 1]]
         symbols = list(self.byte_encoder.values())
         vocab = symbols + [s + "</w>" for s in symbols] + ["".join(m) for m in merges] + _SPECIALS
@@ -88,6 +89,59 @@ class SimpleTokenizer(object):
             ids.extend(self.encoder[s] for s in self._merge_word(mapped))
         return ids
 
+    def vocab_text(self):
+        """the decompressed vocabulary file (what ilvlm_tokenizer_create takes)"""
+        return self._vocab_text
+
     def decode(self, tokens):
         text = "".join(self.decoder[int(t)] for t in tokens)
         return bytearray(self.byte_decoder[c] for c in text).decode("utf-8", errors="replace").replace("</w>", " ")
+
+
+class NativeTokenizer(object):
+    """Batch tokenisation through the C++ BPE of libilvlm_hip.so (ilvlm_tokenizer_*, csrc/tokenizer.cpp): printable-ASCII
+    captions are encoded natively; the rest (non-ASCII, HTML entities) are returned by the library as `fallback` rows and
+    go through SimpleTokenizer above.  Output layout is TextTransformer.tokenize's (text_transformer.py:155-202)."""
+
+    def __init__(self, simple):
+        import ctypes as C
+        from ..... import lib as L
+        self._C, self._L, self.simple = C, L, simple
+        self._h = C.c_void_p()
+        text = simple.vocab_text()
+        L.check(L.load().ilvlm_tokenizer_create(text, len(text), C.byref(self._h)), "tokenizer_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.load().ilvlm_tokenizer_destroy(self._h)
+                self._h = None
+        except Exception:        # interpreter shutdown
+            pass
+
+    def encode_batch(self, texts, ctx, sot, eot):
+        """-> (tokens int64 [n, ctx], pad_mask fp32 [n, ctx], lengths int64 [n]) as torch CPU tensors"""
+        import numpy as np
+        import torch
+        C = self._C
+        n = len(texts)
+        tokens = np.zeros((n, ctx), dtype=np.int64)
+        mask = np.full((n, ctx), -np.inf, dtype=np.float32)
+        lengths = np.ones(n, dtype=np.int32)
+        fallback = np.zeros(n, dtype=np.uint8)
+        # embedded NULs cannot cross a C string: such captions take the Python path
+        raw = [t.encode("utf-8") for t in texts]
+        nul = [i for i, r in enumerate(raw) if b"\0" in r]
+        for i in nul:
+            raw[i] = b"\x7f"
+        arr = (C.c_char_p * n)(*raw)
+        self._L.check(self._L.load().ilvlm_tokenizer_encode(self._h, arr, n, ctx, tokens.ctypes.data, mask.ctypes.data,
+                                                            lengths.ctypes.data, fallback.ctypes.data), "tokenizer_encode")
+        for i in np.nonzero(fallback)[0]:
+            toks = [sot] + self.simple.encode(texts[i]) + [eot]
+            if len(toks) > ctx:
+                toks = [toks[0]] + toks[1:ctx - 1] + [toks[-1]]
+            tokens[i, :len(toks)] = toks
+            mask[i, :len(toks)] = 0
+            lengths[i] = len(toks)
+        return torch.from_numpy(tokens), torch.from_numpy(mask), torch.from_numpy(lengths.astype(np.int64))
