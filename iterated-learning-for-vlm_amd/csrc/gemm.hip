@@ -364,15 +364,21 @@ struct DmaOperand {
 };
 #endif
 
-// fast tile epilogue for SWAP fragments: lane owns row (l&15) and 4 consecutive columns 4*(l>>4).. of each 16x16 tile
+// Tile epilogue for SWAP fragments (lane owns row (l&15) and 4 consecutive columns 4*(l>>4).. of each 16x16 tile).
+// Written that way a wave instruction touches 16 rows x 64 (fp32) / 32 (bf16) bytes.  The vector-memory request rate is
+// what bounds this kernel, so the fragments are first transposed through a wave-private 8 KiB
+// slice of the (now idle) operand LDS: afterwards lane l owns row (l>>4) of a 4-row group and columns 4*(l&15)..+3, and
+// every load / store instruction of the epilogue covers 4 rows x 256 (fp32) / 128 (bf16) contiguous bytes -- a quarter
+// of the requests.  Two passes of 32 rows; all loads of a half-pass are issued before its first store.
 template <int TI, int TJ>
 __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
-                                              float alpha) {
+                                              float alpha, unsigned char* wlds) {
     const ilvlm_gemm_epilogue& e = ep.e;
     const int g = lane >> 4, c = lane & 15;
     const int npre = (e.residual != nullptr) + (e.rowbias != nullptr) +
                      (e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD);
-    const bool fast = ep.vec_ok && !e.accumulate && npre <= 1 && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
+    const bool fast = TJ == 4 && (TI % 2) == 0 && ep.vec_ok && !e.accumulate && npre <= 1 && m_base + TI * 16 <= ep.M &&
+                      n_base + TJ * 16 <= ep.N;
     if (!fast) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -380,45 +386,55 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
             for (int j = 0; j < TJ; ++j) epilogue4<bf16>(ep, m_base + i * 16 + c, n_base + j * 16 + 4 * g, acc[i][j], alpha);
         return;
     }
-    f32x4 bias[TJ];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) bias[j] = e.bias ? *(const f32x4*)(e.bias + n_base + j * 16 + 4 * g) : (f32x4){0, 0, 0, 0};
+    const int n = n_base + 4 * c;                   // this lane's columns after the transpose
+    const f32x4 bias = e.bias ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
     const bool bwd = e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD;
-    constexpr int CH = TI <= 4 ? 1 : 2;            // row-tiles per preload batch (register budget: 4 workgroups per CU)
 #pragma unroll
-    for (int i0 = 0; i0 < TI; i0 += CH) {
-        f32x4 pre[CH][TJ];
-        long off[CH];
+    for (int p = 0; p < TI / 2; ++p) {
+        // fragments of row tiles 2p, 2p+1 -> [32 rows][64 fp32] image, 16-byte chunk index XOR (row & 15)
 #pragma unroll
-        for (int ii = 0; ii < CH; ++ii) {
-            const int m = m_base + (i0 + ii) * 16 + c;
-            off[ii] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n_base + 4 * g;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                if (e.residual) pre[ii][j] = *(const f32x4*)(e.residual + off[ii] + j * 16);
-                else if (e.rowbias) pre[ii][j] = *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * ep.N + n_base + j * 16 + 4 * g);
-                else if (bwd) pre[ii][j] = load4<bf16>((const bf16*)e.aux + off[ii] + j * 16);
+                const int row = ii * 16 + c;
+                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * p + ii][j];
             }
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ii = 0; ii < CH; ++ii)
+        for (int h = 0; h < 2; ++h) {                // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
+            f32x4 pre[4];
+            long off[4];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                f32x4 v = acc[i0 + ii][j] * alpha + bias[j];
-                if (e.rowbias) v += pre[ii][j];
+            for (int k = 0; k < 4; ++k) {
+                const int m = m_base + p * 32 + h * 16 + 4 * k + g;
+                off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
+                if (e.residual) pre[k] = *(const f32x4*)(e.residual + off[k]);
+                else if (e.rowbias) pre[k] = *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * ep.N + n);
+                else if (bwd) pre[k] = load4<bf16>((const bf16*)e.aux + off[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = h * 16 + 4 * k + g;
+                f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
+                v = v * alpha + bias;
+                if (e.rowbias) v += pre[k];
                 if (e.act == ILVLM_ACT_QUICKGELU || e.act == ILVLM_ACT_GELU_ERF) {
-                    store4<bf16>((bf16*)e.aux + off[ii] + j * 16, v);
+                    store4<bf16>((bf16*)e.aux + off[k], v);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = e.act == ILVLM_ACT_QUICKGELU ? quick_gelu(v[k]) : gelu_erf(v[k]);
+                    for (int q = 0; q < 4; ++q) v[q] = e.act == ILVLM_ACT_QUICKGELU ? quick_gelu(v[q]) : gelu_erf(v[q]);
                 } else if (bwd) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        v[k] *= e.act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(pre[ii][j][k]) : gelu_erf_grad(pre[ii][j][k]);
+                    for (int q = 0; q < 4; ++q)
+                        v[q] *= e.act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(pre[k][q]) : gelu_erf_grad(pre[k][q]);
                 }
-                if (e.residual) v += pre[ii][j];
-                if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[ii] + j * 16, v);
-                else store4<bf16>(ep.Cb + off[ii] + j * 16, v);
+                if (e.residual) v += pre[k];
+                if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
+                else store4<bf16>(ep.Cb + off[k], v);
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
     }
 }
 
@@ -578,7 +594,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     if (acc[0][0][0] != 12345.678f) return;
 #endif
     if (SWAP) {
-        epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha);
+        if (NSTAGE > 1) __syncthreads();             // every wave is done with the operand ring
+        epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
     } else {
         const int g = lane >> 4, c = lane & 15;
 #pragma unroll
