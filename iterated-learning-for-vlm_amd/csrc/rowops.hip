@@ -32,7 +32,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     if (t < 0 || t >= vocab) return;
     const float* g = dx + row * W;
     float* d = dtable + t * W;
-    for (int c = lane; c < W; c += 64) atomicAdd(d + c, g[c]);   // 256 contiguous bytes per wave instruction
+    // 256 contiguous bytes per wave instruction.  Rows past <|endoftext|> carry an exactly-zero gradient (nothing
+    // downstream reads them) and all share token id 0: skipping zero addends removes that 1000-way atomic pile-up
+    // on table row 0 without changing the sum.
+    for (int c = lane; c < W; c += 64) {
+        const float v = g[c];
+        if (v != 0.f) atomicAdd(d + c, v);
+    }
 }
 
 // out[l, c] += sum_b x[b, l, c];  out0[c] += sum_b x[b, 0, c]

@@ -110,8 +110,14 @@ class Clip_FDT(ContrastiveBase):
             self._sync("text_done")                # gradient all-reduce of the text ranges waits on this stream
         dqi = e.fdt_bwd(s["fi"], d_fti)            # image side, concurrently
         B, Lv, W = s["B"], s["Lv"], s["W"]
-        dxv = torch.zeros((B * Lv, W), dtype=torch.float32, device=dli.device)
-        dxv_lp = torch.zeros((B * Lv, W), dtype=e.T, device=dli.device) if e.T != torch.float32 else None
+        # token-stream gradient entering the last block: the query head writes every patch row (remapped rows), the
+        # class-token rows get no gradient under FDT
+        dxv = torch.empty((B * Lv, W), dtype=torch.float32, device=dli.device)
+        dxv.view(B, Lv, W)[:, 0].zero_()
+        dxv_lp = None
+        if e.T != torch.float32:
+            dxv_lp = torch.empty((B * Lv, W), dtype=e.T, device=dli.device)
+            dxv_lp.view(B, Lv, W)[:, 0].zero_()
         e.qmap_bwd(s["qi"], "img_query_model.", dqi, dxv, dxv_lp)
         e.vision_bwd(s["vision"], dxv, dxv_lp)
         main.wait_stream(side)
