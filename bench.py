@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--all-text-positions", action="store_true",
+                    help="compute all 77 positions of every caption as the reference does; default: the text tower runs on the "
+                         "valid tokens only (rows behind <|endoftext|> never reach the loss; same logits and gradients)")
     ap.add_argument("--serial-towers", action="store_true",
                     help="run both towers on one stream (used for per-kernel profiles; the headline run overlaps them)")
     return ap.parse_args()
@@ -71,7 +74,7 @@ def synthetic_batch(batch, rank, device):
         tokens[b, 1:n - 1] = torch.randint(0, 49406, (n - 2,), generator=g)
         tokens[b, n - 1] = 49408
         pad[b, :n] = 0
-    return images.to(device), tokens.to(device), pad.to(device)
+    return images.to(device), tokens.to(device), pad.to(device), [int(n) for n in lens]
 
 
 def cpu_baseline(batch=16, steps=2):
@@ -91,7 +94,7 @@ def cpu_baseline(batch=16, steps=2):
         if "logit_scale" in k:
             t = torch.full(s, 2.659)
         p[k] = t.requires_grad_(k != "visual.conv1.weight")
-    images, tokens, pad = synthetic_batch(batch, 0, "cpu")
+    images, tokens, pad, _ = synthetic_batch(batch, 0, "cpu")
     cfg = oracle_cfg(VITB32, FDT_VARIANTS[0])
     m = {k: torch.zeros_like(t) for k, t in p.items()}
     v = {k: torch.zeros_like(t) for k, t in p.items()}
@@ -157,15 +160,20 @@ def main():
     sched = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=opt, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                             warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
     ddp.train()
+    if os.environ.get("ILVLM_GEMM_VARIANT"):          # tuning hook (benchmarks): force one bf16 GEMM kernel
+        ops.gemm_set_variant(int(os.environ["ILVLM_GEMM_VARIANT"]))
     model.engine.concurrent_towers = not args.serial_towers
     crit = ClipInfoCELoss()
-    images, tokens, pad = synthetic_batch(args.batch, rank, dev)
+    images, tokens, pad, lens = synthetic_batch(args.batch, rank, dev)
+    # the resident batch carries its caption lengths as host metadata (what a tokenising data loader knows); with them the
+    # text tower runs on the valid tokens only
+    texts = (tokens, pad) if args.all_text_positions else (tokens, pad, ops.PackedSeq(lens, tokens.shape[1], dev))
     state = dict(step=0)
 
     def one_step():
         state["step"] += 1
         sched.step(state["step"])
-        (li, lt), _ = ddp(images, (tokens, pad))
+        (li, lt), _ = ddp(images, texts)
         loss, target = crit(li, lt)
         loss = loss / world
         prec1, prec5 = accuracy(li, target, topk=(1, 5))
@@ -256,7 +264,11 @@ def main():
                                    "%s compute / fp32 master weights, full train step incl. AdamW" % (
                                        "ViT-B/32" if args.model == "vitb32" else "ViT-L/14 (BASELINE configs[3])", args.precision),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
-                       "context_length": 77, "parallelism": "dp%d" % world},
+                       "context_length": 77, "parallelism": "dp%d" % world,
+                       "caption_tokens": "n ~ U{8..77} per caption (SURVEY.md 8d), %d valid of %d positions on rank 0" % (
+                           sum(lens), len(lens) * 77),
+                       "text_rows": "all positions" if args.all_text_positions else
+                                    "valid tokens only (packed rows; positions behind <|endoftext|> never reach the loss)"},
             "step_mfma_frac": round(value / world * FLOPS_PER_PAIR[args.model] / (PEAK_BF16 * 1e12), 4),
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(1000.0 * host_dt / args.steps, 3),
             "roofline": roofline, "cpu_baseline": cpu,

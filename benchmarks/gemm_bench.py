@@ -11,11 +11,14 @@ for tag, M, E in (("vit", 12800, 768), ("txt", 19712, 512)):
         SHAPES.append((tag + "." + name + ".fwd", 0, 0, M, n, k, False, 1))
         SHAPES.append((tag + "." + name + ".dgrad", 0, 1, M, k, n, False, 1))
         SHAPES.append((tag + "." + name + ".wgrad", 1, 1, n, k, M, True, ops.wgrad_split(n, k, M)))
+for (tag, M, N, K) in [("pk.qkv.fwd", 11319, 1536, 512), ("pk.out.fwd", 11319, 512, 512), ("pk.fc.fwd", 11319, 2048, 512),
+                       ("pk.proj.fwd", 11319, 512, 2048)]:
+    SHAPES.append((tag, 0, 0, M, N, K, False, 1))
 SHAPES.append(("fdt.img.scores", 0, 0, 12544, 4096, 512, False, 1))
 SHAPES.append(("fdt.txt.scores", 0, 0, 19712, 4096, 512, False, 1))
 
 
-def run(variants=(0, 5, 7), rounds=5, only=None):
+def run(variants=(0, 5, 6, 7), rounds=5, only=None):
     torch.manual_seed(0)
     res = {}
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:

@@ -79,7 +79,7 @@ typedef struct ilvlm_gemm_epilogue {
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
 /* bf16 kernel selection (tuning / tests): 0 register-staged general kernel, 5 direct-to-LDS 128x128 (default),
- * 7 direct-to-LDS 256x128 with a 3-stage ring.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
+ * 6 direct-to-LDS 64x128 (K-contiguous A operand), 7 direct-to-LDS 256x128 with a 3-stage ring.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
  * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 
@@ -192,6 +192,31 @@ typedef struct ilvlm_adamw_hyper {
 int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                      const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
                      int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream);
+
+/* ---- packed text rows.  Positions behind <|endoftext|> never reach the loss: attention is causal
+ * (text_transformer.py:147-153), the FDT scores of masked tokens are multiplied by zero (clip_fdt.py:118-123) and the
+ * pooled feature is read at the EOT position (text_transformer.py:248).  The training step therefore may run the text
+ * tower on the valid tokens only: sequence b owns rows [seq_offs[b], seq_offs[b+1]) of every [rows, W] text tensor
+ * (seq_offs: int32[B+1] on the device, seq_offs[0] = 0, lengths 1..L).  `tokens` keeps the reference's [B][L] layout.
+ * These entry points are the packed forms of the functions above; results on the valid rows are the same. */
+int ilvlm_embed_packed_fwd(const int64_t* tokens, const int32_t* seq_offs, const float* table, const float* pos, float* x,
+                           int B, int L, int W, int vocab, void* stream);
+int ilvlm_embed_packed_bwd(const int64_t* tokens, const int32_t* seq_offs, const float* dx, float* dtable, float* dpos,
+                           int B, int L, int W, int vocab, void* stream);
+/* L = row stride of lse ([B][H][L]) = context length; Lcap = longest sequence of this batch (<= 128 bf16, 80 f32) */
+int ilvlm_attention_packed_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
+                               const int32_t* seq_offs, void* stream);
+int ilvlm_attention_packed_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype,
+                               int B, int L, int Lcap, int H, int causal, const int32_t* seq_offs, void* stream);
+/* idx[b] = position inside sequence b (EOT pooling, text_transformer.py:248) */
+int ilvlm_gather_packed_rows(const float* x, const int64_t* idx, const int32_t* seq_offs, float* y, int B, int W, void* stream);
+int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, const int32_t* seq_offs, float* dx, int B, int W,
+                              void* stream);
+/* scores [rows][C] on packed rows; the T - len masked positions count as the zeros the dense form gives them */
+int ilvlm_fdt_pool_packed_fwd(const float* scores, const int32_t* seq_offs, float* pooled, int* argmax, int B, int T, int C,
+                              float sqrt_d, float temperature, int pool, void* stream);
+int ilvlm_fdt_pool_packed_bwd(const float* dpooled, const int* argmax, const int32_t* seq_offs, void* dscores, int dtype,
+                              int B, int T, int C, float sqrt_d, float temperature, int pool, void* stream);
 
 /* ---- host-side byte-level BPE tokenizer (no GPU work).  Replaces SimpleTokenizer.encode / bpe
  * (prototype/model/utils/text_utils/simple_tokenizer.py:63-135) and TextTransformer.tokenize framing

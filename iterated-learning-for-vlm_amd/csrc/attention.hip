@@ -91,7 +91,8 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16* src, long row_stride, 
 // ---------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                         float* __restrict__ lse, int L, int H, int causal) {
+                                                         float* __restrict__ lse, int Lmax, int H, int causal,
+                                                         const int* __restrict__ seq_offs) {
     constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Ks = (bf16*)smem_raw;          // [ROWS][72]
@@ -100,7 +101,10 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = HD * H;
     const long rs = 3L * E;
-    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    // dense layout: sequence b = rows [b*Lmax, (b+1)*Lmax); packed layout: rows [seq_offs[b], seq_offs[b+1])
+    const long row0 = seq_offs ? seq_offs[b] : (long)b * Lmax;
+    const int L = seq_offs ? seq_offs[b + 1] - seq_offs[b] : Lmax;
+    const bf16* base = qkv + row0 * rs + h * HD;
     const int g = lane >> 4, c16 = lane & 15;
     const int q = wave * 16 + c16;
     // the wave's Q tile as B operand (column = query), pre-scaled by 1/sqrt(64) (exact in bf16)
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
     stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
     stage_rows<ROWS, NTH>(Vs, base + 2 * E, rs, L, 1.0f, tid);
     __syncthreads();
+    if (wave * 16 >= L) return;                        // a shorter packed sequence: this tile has no rows (after the only barrier)
 
     const int nkt = causal ? min(NT, wave + 1) : NT;   // key tiles this query tile can see (wave-uniform)
     f32x4 s[NT];                                       // s[kt][r] = S[q][key = 16 kt + 4 g + r]
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
     }
     t = group4_sum(t);
     const float inv = 1.0f / t;
-    if (g == 0 && q < L) lse[((long)b * H + h) * L + q] = m + __logf(t);
+    if (g == 0 && q < L) lse[((long)b * H + h) * Lmax + q] = m + __logf(t);
     bf16x4 pk[NTE];
 #pragma unroll
     for (int kt = 0; kt < NTE; ++kt) {
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
                                                             pack8(pk[2 * kp], pk[2 * kp + 1]), o, 0, 0, 0);
         if (q < L) {
             bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-            *(bf16x4*)(out + ((long)b * L + q) * E + h * HD + dt * 16 + 4 * g) = ov;
+            *(bf16x4*)(out + (row0 + q) * E + h * HD + dt * 16 + 4 * g) = ov;
         }
     }
 }
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
                                                          const bf16* __restrict__ outp, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int L, int H, int causal) {
+                                                         bf16* __restrict__ dqkv, int Lmax, int H, int causal,
+                                                         const int* __restrict__ seq_offs) {
     constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Qs = (bf16*)smem_raw;          // [ROWS][72], pre-scaled by 1/8
@@ -186,12 +192,14 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = HD * H;
     const long rs = 3L * E;
-    const bf16* base = qkv + (long)b * L * rs + h * HD;
+    const long row0 = seq_offs ? seq_offs[b] : (long)b * Lmax;
+    const int L = seq_offs ? seq_offs[b + 1] - seq_offs[b] : Lmax;
+    const bf16* base = qkv + row0 * rs + h * HD;
     const bf16* vbase = base + 2 * E;
     stage_rows<ROWS, NTH>(Qs, base, rs, L, 0.125f, tid);
     stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
-    const bf16* dob = dout + (long)b * L * E + h * HD;
-    const bf16* ob = outp + (long)b * L * E + h * HD;
+    const bf16* dob = dout + row0 * E + h * HD;
+    const bf16* ob = outp + row0 * E + h * HD;
     constexpr int ITER = (ROWS * 8 + NTH - 1) / NTH;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {     // uniform trip count: every lane takes part in the shuffles
@@ -213,8 +221,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
             if (ch == 0) delta[r] = part;
         }
     }
-    for (int r = tid; r < ROWS; r += NTH) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
+    for (int r = tid; r < ROWS; r += NTH) lses[r] = r < L ? lse[((long)b * H + h) * Lmax + r] : 0.f;
     __syncthreads();
+    if (wave * 16 >= L) return;                        // shorter packed sequence: no rows in this tile
 
     const int g = lane >> 4, c16 = lane & 15;
     {   // ---- pass A: dQ of query tile `wave`.  Transposed products: lane (g, c16 = q) holds keys 16 kt + 4 g + r.
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
                                                                   pack8(ds[2 * kp], ds[2 * kp + 1]), acc, 0, 0, 0);
             if (q < L) {
                 bf16x4 ov = {(bf16)(acc[0] * 0.125f), (bf16)(acc[1] * 0.125f), (bf16)(acc[2] * 0.125f), (bf16)(acc[3] * 0.125f)};
-                *(bf16x4*)(dqkv + ((long)b * L + q) * rs + h * HD + dt * 16 + 4 * g) = ov;
+                *(bf16x4*)(dqkv + (row0 + q) * rs + h * HD + dt * 16 + 4 * g) = ov;
             }
         }
     }
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 kv = {(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
                 bf16x4 vv = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
-                bf16* o = dqkv + ((long)b * L + key) * rs + h * HD + dt * 16 + 4 * g;
+                bf16* o = dqkv + (row0 + key) * rs + h * HD + dt * 16 + 4 * g;
                 *(bf16x4*)(o + E) = kv;
                 *(bf16x4*)(o + 2 * E) = vv;
             }
@@ -562,7 +571,10 @@ __device__ __forceinline__ void load_rows_f32(float* dst, const float* src, long
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qkv, float* __restrict__ out,
-                                                    float* __restrict__ lse, int L, int H, int causal) {
+                                                    float* __restrict__ lse, int Lmax, int H, int causal,
+                                                    const int* __restrict__ seq_offs) {
+    const long row0 = seq_offs ? seq_offs[blockIdx.x / H] : (long)(blockIdx.x / H) * Lmax;
+    const int L = seq_offs ? seq_offs[blockIdx.x / H + 1] - seq_offs[blockIdx.x / H] : Lmax;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Qs = (float*)smem_raw;
     float* Ks = Qs + L * LDF;
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qk
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = HD * H;
     const long rs = 3L * E;
-    const float* base = qkv + (long)b * L * rs + h * HD;
+    const float* base = qkv + row0 * rs + h * HD;
     load_rows_f32(Qs, base, rs, L, 0.125f, tid);
     load_rows_f32(Ks, base + E, rs, L, 1.0f, tid);
     load_rows_f32(Vs, base + 2 * E, rs, L, 1.0f, tid);
@@ -594,20 +606,23 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qk
         for (int k = lane; k < L; k += 64) t += __expf(S[q * LS + k] - m);
         t = wave_sum(t);
         for (int k = lane; k < L; k += 64) S[q * LS + k] = __expf(S[q * LS + k] - m) / t;
-        if (lane == 0) lse[((long)b * H + h) * L + q] = m + __logf(t);
+        if (lane == 0) lse[((long)b * H + h) * Lmax + q] = m + __logf(t);
     }
     __syncthreads();
     for (int i = tid; i < L * HD; i += 256) {
         int q = i >> 6, d = i & 63;
         float o = 0.f;
         for (int k = 0; k < L; ++k) o = fmaf(S[q * LS + k], Vs[k * LDF + d], o);
-        out[((long)b * L + q) * E + h * HD + d] = o;
+        out[(row0 + q) * E + h * HD + d] = o;
     }
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                     const float* __restrict__ outp, const float* __restrict__ lse,
-                                                    float* __restrict__ dqkv, int L, int H, int causal) {
+                                                    float* __restrict__ dqkv, int Lmax, int H, int causal,
+                                                    const int* __restrict__ seq_offs) {
+    const long row0 = seq_offs ? seq_offs[blockIdx.x / H] : (long)(blockIdx.x / H) * Lmax;
+    const int L = seq_offs ? seq_offs[blockIdx.x / H + 1] - seq_offs[blockIdx.x / H] : Lmax;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Qs = (float*)smem_raw;
     float* Ks = Qs + L * LDF;
@@ -621,12 +636,12 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ do
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = HD * H;
     const long rs = 3L * E;
-    const float* base = qkv + (long)b * L * rs + h * HD;
+    const float* base = qkv + row0 * rs + h * HD;
     load_rows_f32(Qs, base, rs, L, 0.125f, tid);
     load_rows_f32(Ks, base + E, rs, L, 1.0f, tid);
     load_rows_f32(Vs, base + 2 * E, rs, L, 1.0f, tid);
-    const float* dob = dout + (long)b * L * E + h * HD;
-    const float* ob = outp + (long)b * L * E + h * HD;
+    const float* dob = dout + row0 * E + h * HD;
+    const float* ob = outp + row0 * E + h * HD;
     load_rows_f32(dOs, dob, E, L, 1.0f, tid);
     for (int q = wave; q < L; q += 4) {
         float t = dob[(long)q * E + lane] * ob[(long)q * E + lane];
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ do
             s = fmaf(Qs[q * LDF + d], Ks[k * LDF + d], s);
             dp = fmaf(dOs[q * LDF + d], Vs[k * LDF + d], dp);
         }
-        float p = (causal && k > q) ? 0.f : __expf(s - lse[((long)b * H + h) * L + q]);
+        float p = (causal && k > q) ? 0.f : __expf(s - lse[((long)b * H + h) * Lmax + q]);
         P[q * LS + k] = p;
         dS[q * LS + k] = p * (dp - delta[q]);
     }
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ do
             dk = fmaf(dS[j * LS + r], Qs[j * LDF + d], dk);
             dq = fmaf(dS[r * LS + j], Ks[j * LDF + d], dq);
         }
-        float* o = dqkv + ((long)b * L + r) * rs + h * HD + d;
+        float* o = dqkv + (row0 + r) * rs + h * HD + d;
         o[0] = dq * 0.125f;
         o[E] = dk;
         o[2 * E] = dv;
@@ -684,19 +699,21 @@ int launch_fwd_bf16(const bf16* qkv, bf16* out, float* lse, int B, int L, int H,
     return ILVLM_OK;
 }
 template <int NT>
-int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, hipStream_t s) {
+int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, const int* seq_offs,
+                    hipStream_t s) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 2 * ROWS * LDH * 2;
-    hipLaunchKernelGGL((attn_fwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, qkv, out, lse, L, H, causal);
+    hipLaunchKernelGGL((attn_fwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, qkv, out, lse, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_fwd");
     return ILVLM_OK;
 }
 template <int NT>
 int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
-                    int causal, hipStream_t s) {
+                    int causal, const int* seq_offs, hipStream_t s) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // <= 57 KB: below the 64 KB default limit
-    hipLaunchKernelGGL((attn_bwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
+    hipLaunchKernelGGL((attn_bwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal,
+                       seq_offs);
     ILVLM_LAUNCH_CHECK("attention_bwd");
     return ILVLM_OK;
 }
@@ -718,24 +735,27 @@ int launch_bwd_tiled_bf16(const bf16* dout, const bf16* qkv, const bf16* out, co
 
 }  // namespace
 
-extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
-                                   void* stream) {
+// Lcap: longest sequence of the launch (tile count / LDS size); L: row stride of lse and, for the dense layout
+// (seq_offs == nullptr), the length of every sequence
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
+                              const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
-    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_fwd: bad shape B=%d L=%d H=%d", B, L, H);
+    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0 && Lcap > 0 && Lcap <= L, "attention_fwd: bad shape B=%d L=%d Lcap=%d H=%d", B, L, Lcap, H);
+    ILVLM_REQUIRE(!seq_offs || Lcap <= (dtype == ILVLM_BF16 ? 128 : 96), "attention_fwd: packed rows support sequences up to 128 (bf16) / 96 (f32) tokens");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ILVLM_BF16) {
         ILVLM_REQUIRE(L <= 288, "attention_fwd(bf16): L=%d > 288 not supported", L);
         const bf16* q = (const bf16*)qkv;
         bf16* o = (bf16*)out;
-        switch ((L + 15) / 16) {
-            case 1: return launch_fwd_wave<1>(q, o, lse, B, L, H, causal, s);
-            case 2: return launch_fwd_wave<2>(q, o, lse, B, L, H, causal, s);
-            case 3: return launch_fwd_wave<3>(q, o, lse, B, L, H, causal, s);
-            case 4: return launch_fwd_wave<4>(q, o, lse, B, L, H, causal, s);
-            case 5: return launch_fwd_wave<5>(q, o, lse, B, L, H, causal, s);
-            case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, s);
-            case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, s);
-            case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, s);
+        switch ((Lcap + 15) / 16) {
+            case 1: return launch_fwd_wave<1>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 2: return launch_fwd_wave<2>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 3: return launch_fwd_wave<3>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 4: return launch_fwd_wave<4>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 5: return launch_fwd_wave<5>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, seq_offs, s);
             default: break;
         }
         if (L <= 192) return launch_fwd_bf16<192>(q, o, lse, B, L, H, causal, s);
@@ -744,36 +764,46 @@ extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int d
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_fwd: bad dtype %d", dtype);
     ILVLM_REQUIRE(L <= 96, "attention_fwd(f32): L=%d > 96 not supported", L);
-    int bytes = (3 * L * LDF + L * (L + 1)) * 4;
+    int bytes = (3 * Lcap * LDF + Lcap * (Lcap + 1)) * 4;
     static bool done_f = false;
     if (!done_f) {
         int rc = set_lds(attn_fwd_f32, 160 * 1024, "attention_fwd_f32");
         if (rc) return rc;
         done_f = true;
     }
-    hipLaunchKernelGGL(attn_fwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)qkv, (float*)out, lse, L, H, causal);
+    hipLaunchKernelGGL(attn_fwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)qkv, (float*)out, lse, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_fwd_f32");
     return ILVLM_OK;
 }
+extern "C" int ilvlm_attention_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int H, int causal,
+                                   void* stream) {
+    return attention_fwd_impl(qkv, out, lse, dtype, B, L, L, H, causal, nullptr, stream);
+}
+extern "C" int ilvlm_attention_packed_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H,
+                                          int causal, const int32_t* seq_offs, void* stream) {
+    ILVLM_REQUIRE(seq_offs, "attention_packed_fwd: null seq_offs");
+    return attention_fwd_impl(qkv, out, lse, dtype, B, L, Lcap, H, causal, seq_offs, stream);
+}
 
-extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv,
-                                   int dtype, int B, int L, int H, int causal, void* stream) {
+static int attention_bwd_impl(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype,
+                              int B, int L, int Lcap, int H, int causal, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(dout && qkv && out && lse && dqkv, "attention_bwd: null pointer");
-    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0, "attention_bwd: bad shape B=%d L=%d H=%d", B, L, H);
+    ILVLM_REQUIRE(B > 0 && L > 0 && H > 0 && Lcap > 0 && Lcap <= L, "attention_bwd: bad shape B=%d L=%d Lcap=%d H=%d", B, L, Lcap, H);
+    ILVLM_REQUIRE(!seq_offs || Lcap <= (dtype == ILVLM_BF16 ? 128 : 80), "attention_bwd: packed rows support sequences up to 128 (bf16) / 80 (f32) tokens");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ILVLM_BF16) {
         ILVLM_REQUIRE(L <= 288, "attention_bwd(bf16): L=%d > 288 not supported", L);
         const bf16 *d = (const bf16*)dout, *q = (const bf16*)qkv, *o = (const bf16*)out;
         bf16* dq = (bf16*)dqkv;
-        switch ((L + 15) / 16) {
-            case 1: return launch_bwd_wave<1>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 2: return launch_bwd_wave<2>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 3: return launch_bwd_wave<3>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 4: return launch_bwd_wave<4>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 5: return launch_bwd_wave<5>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, s);
-            case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, s);
+        switch ((Lcap + 15) / 16) {
+            case 1: return launch_bwd_wave<1>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 2: return launch_bwd_wave<2>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 3: return launch_bwd_wave<3>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 4: return launch_bwd_wave<4>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 5: return launch_bwd_wave<5>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
             default: break;
         }
         if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s);
@@ -782,7 +812,7 @@ extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_bwd: bad dtype %d", dtype);
     ILVLM_REQUIRE(L <= 80, "attention_bwd(f32): L=%d > 80 not supported", L);
-    int bytes = (4 * L * LDF + 2 * L * (L + 1) + L) * 4;
+    int bytes = (4 * Lcap * LDF + 2 * Lcap * (Lcap + 1) + Lcap) * 4;
     static bool done_b = false;
     if (!done_b) {
         int rc = set_lds(attn_bwd_f32, 160 * 1024, "attention_bwd_f32");
@@ -790,7 +820,17 @@ extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void
         done_b = true;
     }
     hipLaunchKernelGGL(attn_bwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)dout, (const float*)qkv,
-                       (const float*)out, lse, (float*)dqkv, L, H, causal);
+                       (const float*)out, lse, (float*)dqkv, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_bwd_f32");
     return ILVLM_OK;
+}
+extern "C" int ilvlm_attention_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv,
+                                   int dtype, int B, int L, int H, int causal, void* stream) {
+    return attention_bwd_impl(dout, qkv, out, lse, dqkv, dtype, B, L, L, H, causal, nullptr, stream);
+}
+extern "C" int ilvlm_attention_packed_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv,
+                                          int dtype, int B, int L, int Lcap, int H, int causal, const int32_t* seq_offs,
+                                          void* stream) {
+    ILVLM_REQUIRE(seq_offs, "attention_packed_bwd: null seq_offs");
+    return attention_bwd_impl(dout, qkv, out, lse, dqkv, dtype, B, L, Lcap, H, causal, seq_offs, stream);
 }

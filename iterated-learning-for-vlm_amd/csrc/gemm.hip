@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
 //                          ([rows][32 k] 64-byte rows: slot c ^ ((r >> 2) & 3))
 //   K-strided operand    : [k][rows] rows*2-byte rows, chunk c of k-row r stored at slot (c & ~15) | ((c & 15) ^ swz16(r)),
 //                          swz16(r) = ((r & 3) << 2) | ((r >> 2) & 3)  (conflict-free for ds_read_b64_tr_b16)
-// Requirements (checked on the host): K % 64 == 0; a K-strided operand needs rows % 8 == 0.
+// Requirements (checked on the host): K % 64 == 0 unless both operands are K-strided (their k-rows past K are beyond the
+// buffer extent and read as zeros); a K-strided operand needs rows % 8 == 0.
 // =====================================================================================
 __device__ __forceinline__ int swz16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     if (!SWAP) { tm = wg % tiles_m; z = wg / tiles_m; }
     else { z = wg % split_k; tm = wg / split_k; }
     const int m0 = tm * DBM, n0 = tn * DBN;
-    const int nt_total = K / BKT;
+    const int nt_total = (K + BKT - 1) / BKT;          // a partial last tile only with two K-strided operands (host check)
     const int per = (nt_total + split_k - 1) / split_k;
     const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
     if (t_begin >= t_end) return;
@@ -740,7 +741,9 @@ int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, i
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT = 64>
 int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
     auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT>;
-    constexpr int bytes = NSTAGE * (DBM + DBN) * BKT * 2;
+    // operand ring; the SWAP epilogue transposes through 8 KiB per wave of the same allocation
+    constexpr int ring = NSTAGE * (DBM + DBN) * BKT * 2, epi = SWAP ? WM * WN * 8192 : 0;
+    constexpr int bytes = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -766,8 +769,8 @@ int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, 
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-// 0 = register-staged general kernel only; 5 = direct-to-LDS 128x128 single stage (default: fastest on the ViT-B/32
-// shapes, benchmarks/gemm_bench.py); 7 = direct-to-LDS 256x128, 8 waves, 3-stage ring.  (Round-1 exploration also
+// 0 = register-staged general kernel only; 5 = direct-to-LDS 128x128 single stage (default: fastest inside the step);
+// 6 = 64x128 tiles where the A operand is K-contiguous; 7 = direct-to-LDS 256x128, 8 waves, 3-stage ring.  (Round-1 exploration also
 // measured global_load_lds addressing, double buffering, 256x256 and BK=32 variants -- all slower; see DESIGN.md.)
 int g_gemm_variant = 5;
 
@@ -814,15 +817,24 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bf16* b = (const bf16*)B;
         const bool swap = !epi->accumulate;
         const int variant = g_gemm_variant;
-        const bool fast = variant != 0 && (K % BK == 0) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
+        // K-contiguous operands need whole K-tiles (a partial one would run into the next row); when both operands are
+        // K-strided (weight gradients: the contraction runs over token rows) the k-rows past K lie beyond the buffer
+        // descriptors' extent and read as zeros, so any K works -- the packed text rows need exactly that.
+        const bool fast = variant != 0 && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
         if (fast) {
-            // 5 (default) = 128x128 / 4 waves / 1 stage (4 workgroups per CU); 7 = 256x128 / 8 waves / 3-stage ring
+            // 5 (default) = 128x128 / 4 waves / 1 stage (4 workgroups per CU); 7 = 256x128 / 8 waves / 3-stage ring;
+            // 6 = 64x128 tiles (K-contiguous A only).  6 is 3..27 % faster in isolation on launches that leave most
+            // of the chip's 1024 workgroup slots empty (N = 512 / 768 outputs, the packed text rows;
+            // benchmarks/gemm_bench.py) but 6.5 % SLOWER inside the two-stream step, where the other tower's kernels
+            // fill those slots and the doubled weight re-reads cost more -- so it is never selected automatically.
 #define ILVLM_DMA(TA, TB)                                                                                            \
     do {                                                                                                             \
         if (variant == 7)                                                                                            \
             return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
                         : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
+        if (swap && !trans_a && variant == 6)                                                                        \
+            return launch_dma<TA, TB, true, 64, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);              \
         return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
                     : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
     } while (0)
@@ -856,7 +868,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 7, "gemm_set_variant: 0, 5 or 7");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 7), "gemm_set_variant: 0, 5, 6 or 7");
     g_gemm_variant = variant;
     return ILVLM_OK;
 }

@@ -9,26 +9,41 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // token embedding (reference text_transformer.py:228-231); one wave per token row
 // ------------------------------------------------------------------------------------------------
+// Row layout of the token stream: dense = row b*L + l for every position; packed (seq_offs != nullptr) = only the
+// first len_b = seq_offs[b+1] - seq_offs[b] positions of sequence b, at rows seq_offs[b] + l.  Positions past
+// <|endoftext|> never reach the loss (causal attention, masked FDT scores, EOT pooling), so the training step runs
+// the text tower on the packed rows.
+__device__ __forceinline__ long token_row(const int* seq_offs, int b, int l, int L) {
+    if (!seq_offs) return (long)b * L + l;
+    return l < seq_offs[b + 1] - seq_offs[b] ? (long)seq_offs[b] + l : -1;
+}
+
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ table,
-                                                        const float* __restrict__ pos, float* __restrict__ x, long rows,
-                                                        int L, int W, int vocab) {
+                                                        const float* __restrict__ pos, float* __restrict__ x, int B,
+                                                        int L, int W, int vocab, const int* __restrict__ seq_offs) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    long t = tok[row];
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b, l) pair
+    if (i >= (long)B * L) return;
+    const int b = i / L, l = i % L;
+    const long row = token_row(seq_offs, b, l, L);
+    if (row < 0) return;
+    long t = tok[i];
     t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);   // clamp: never read out of the table
     const float* e = table + t * W;
-    const float* p = pos + (row % L) * (long)W;
+    const float* p = pos + l * (long)W;
     float* o = x + row * W;
     for (int c = lane * 4; c < W; c += 256) *(f32x4*)(o + c) = *(const f32x4*)(e + c) + *(const f32x4*)(p + c);
 }
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dx,
-                                                        float* __restrict__ dtable, long rows, int W, int vocab) {
+                                                        float* __restrict__ dtable, int B, int L, int W, int vocab,
+                                                        const int* __restrict__ seq_offs) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    long t = tok[row];
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= (long)B * L) return;
+    const long row = token_row(seq_offs, i / L, i % L, L);
+    if (row < 0) return;
+    long t = tok[i];
     if (t < 0 || t >= vocab) return;
     const float* g = dx + row * W;
     float* d = dtable + t * W;
@@ -43,11 +58,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 
 // out[l, c] += sum_b x[b, l, c];  out0[c] += sum_b x[b, 0, c]
 __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                        float* __restrict__ out0, int B, int L, int W, int bchunk) {
+                                                        float* __restrict__ out0, int B, int L, int W, int bchunk,
+                                                        const int* __restrict__ seq_offs) {
     const int l = blockIdx.x, b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
     for (int c = threadIdx.x; c < W; c += 256) {
         float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += x[((long)b * L + l) * W + c];
+        for (int b = b0; b < b1; ++b) {
+            const long row = token_row(seq_offs, b, l, L);
+            if (row >= 0) s += x[row * W + c];
+        }
         atomicAdd(out + (long)l * W + c, s);
         if (out0 && l == 0) atomicAdd(out0 + c, s);
     }
@@ -81,40 +100,51 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
-                                                          float* __restrict__ y, int B, int L, int W) {
+                                                          float* __restrict__ y, int B, int L, int W,
+                                                          const int* __restrict__ seq_offs) {
     const int b = blockIdx.x;
+    const int len = seq_offs ? seq_offs[b + 1] - seq_offs[b] : L;
     long r = idx[b];
-    r = r < 0 ? 0 : (r >= L ? L - 1 : r);
-    for (int c = threadIdx.x; c < W; c += 256) y[(long)b * W + c] = x[((long)b * L + r) * W + c];
+    r = r < 0 ? 0 : (r >= len ? len - 1 : r);
+    const long row = (seq_offs ? (long)seq_offs[b] : (long)b * L) + r;
+    for (int c = threadIdx.x; c < W; c += 256) y[(long)b * W + c] = x[row * W + c];
 }
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dy, const int64_t* __restrict__ idx,
-                                                           float* __restrict__ dx, int B, int L, int W) {
+                                                           float* __restrict__ dx, int B, int L, int W,
+                                                           const int* __restrict__ seq_offs) {
     const int b = blockIdx.x;
+    const int len = seq_offs ? seq_offs[b + 1] - seq_offs[b] : L;
     long r = idx[b];
-    if (r < 0 || r >= L) return;
-    for (int c = threadIdx.x; c < W; c += 256) dx[((long)b * L + r) * W + c] += dy[(long)b * W + c];
+    if (r < 0 || r >= len) return;
+    const long row = (seq_offs ? (long)seq_offs[b] : (long)b * L) + r;
+    for (int c = threadIdx.x; c < W; c += 256) dx[row * W + c] += dy[(long)b * W + c];
 }
 
 // ------------------------------------------------------------------------------------------------
 // FDT pooling over tokens (reference clip_fdt.py:118-145): order of operations kept:
 //   v = ((s / sqrt_d) * keep) / temperature
 // ------------------------------------------------------------------------------------------------
+// Packed rows (seq_offs): only the valid tokens have a score row; the masked positions behind them contribute the
+// value the dense form gives them, (s * 0) / temperature = 0 -- to the maximum (argmax = first masked position, whose
+// gradient is multiplied by the zero mask), to the sum, and to the mean's divisor T.
 __global__ __launch_bounds__(256) void fdt_pool_fwd_kernel(const float* __restrict__ s, const float* __restrict__ mask,
                                                            float* __restrict__ pooled, int* __restrict__ argmax, int T, int C,
-                                                           float sqrt_d, float temp, int pool) {
+                                                           float sqrt_d, float temp, int pool, const int* __restrict__ seq_offs) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float* sb = s + (long)b * T * C + c;
+    const int len = seq_offs ? seq_offs[b + 1] - seq_offs[b] : T;
+    const float* sb = s + (seq_offs ? (long)seq_offs[b] : (long)b * T) * C + c;
     float acc = pool == ILVLM_POOL_MAX ? -INFINITY : 0.f;
     int am = 0;
-    for (int t = 0; t < T; ++t) {
-        float keep = (mask == nullptr || mask[(long)b * T + t] == 0.f) ? 1.f : 0.f;
+    for (int t = 0; t < len; ++t) {
+        float keep = (seq_offs || mask == nullptr || mask[(long)b * T + t] == 0.f) ? 1.f : 0.f;
         float v = ((sb[(long)t * C] / sqrt_d) * keep) / temp;
         if (pool == ILVLM_POOL_MAX) {
             if (v > acc) { acc = v; am = t; }   // first maximum wins (torch.max semantics)
         } else acc += v;
     }
+    if (len < T && pool == ILVLM_POOL_MAX && 0.f > acc) { acc = 0.f; am = len; }
     if (pool == ILVLM_POOL_MEAN) acc = acc / T;
     pooled[(long)b * C + c] = acc;
     if (argmax) argmax[(long)b * C + c] = am;
@@ -123,16 +153,17 @@ __global__ __launch_bounds__(256) void fdt_pool_fwd_kernel(const float* __restri
 template <class T_>
 __global__ __launch_bounds__(256) void fdt_pool_bwd_kernel(const float* __restrict__ dp, const int* __restrict__ argmax,
                                                            const float* __restrict__ mask, T_* __restrict__ ds, int T, int C,
-                                                           float sqrt_d, float temp, int pool) {
+                                                           float sqrt_d, float temp, int pool, const int* __restrict__ seq_offs) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float g = dp[(long)b * C + c] / temp / sqrt_d;
     if (pool == ILVLM_POOL_MEAN) g = g / T;
     const int am = pool == ILVLM_POOL_MAX ? argmax[(long)b * C + c] : -1;
-    T_* db = ds + (long)b * T * C + c;
-    for (int t = 0; t < T; ++t) {
-        float keep = (mask == nullptr || mask[(long)b * T + t] == 0.f) ? 1.f : 0.f;
+    const int len = seq_offs ? seq_offs[b + 1] - seq_offs[b] : T;
+    T_* db = ds + (seq_offs ? (long)seq_offs[b] : (long)b * T) * C + c;
+    for (int t = 0; t < len; ++t) {
+        float keep = (seq_offs || mask == nullptr || mask[(long)b * T + t] == 0.f) ? 1.f : 0.f;
         float v = (pool != ILVLM_POOL_MAX || t == am) ? g * keep : 0.f;
         db[(long)t * C] = from_f<T_>(v);
     }
@@ -348,29 +379,48 @@ inline int grid_1d(long n, int per_block, int cap = 4096) {
 
 #define S_ ((hipStream_t)stream)
 
-extern "C" int ilvlm_embed_fwd(const int64_t* tokens, const float* table, const float* pos, float* x, int B, int L, int W,
-                               int vocab, void* stream) {
+static int embed_fwd_impl(const int64_t* tokens, const float* table, const float* pos, float* x, int B, int L, int W,
+                          int vocab, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(tokens && table && pos && x && B > 0 && L > 0 && W > 0 && W % 4 == 0 && vocab > 0, "embed_fwd: bad args");
-    long rows = (long)B * L;
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, S_, tokens, table, pos, x, rows, L, W, vocab);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, S_, tokens, table, pos, x, B, L, W, vocab, seq_offs);
     ILVLM_LAUNCH_CHECK("embed_fwd");
     return ILVLM_OK;
 }
-extern "C" int ilvlm_embed_bwd(const int64_t* tokens, const float* dx, float* dtable, float* dpos, int B, int L, int W,
-                               int vocab, void* stream) {
-    ILVLM_REQUIRE(tokens && dx && dtable && B > 0 && L > 0 && W > 0 && vocab > 0, "embed_bwd: bad args");
-    long rows = (long)B * L;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, S_, tokens, dx, dtable, rows, W, vocab);
-    ILVLM_LAUNCH_CHECK("embed_bwd");
-    if (dpos) return ilvlm_batch_sum(dx, dpos, nullptr, B, L, W, stream);
-    return ILVLM_OK;
-}
-extern "C" int ilvlm_batch_sum(const float* x, float* out, float* out0, int B, int L, int W, void* stream) {
+static int batch_sum_impl(const float* x, float* out, float* out0, int B, int L, int W, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(x && out && B > 0 && L > 0 && W > 0, "batch_sum: bad args");
     int bchunk = 32;
-    hipLaunchKernelGGL(batch_sum_kernel, dim3(L, ceil_div(B, bchunk)), dim3(256), 0, S_, x, out, out0, B, L, W, bchunk);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(L, ceil_div(B, bchunk)), dim3(256), 0, S_, x, out, out0, B, L, W, bchunk, seq_offs);
     ILVLM_LAUNCH_CHECK("batch_sum");
     return ILVLM_OK;
+}
+static int embed_bwd_impl(const int64_t* tokens, const float* dx, float* dtable, float* dpos, int B, int L, int W, int vocab,
+                          const int* seq_offs, void* stream) {
+    ILVLM_REQUIRE(tokens && dx && dtable && B > 0 && L > 0 && W > 0 && vocab > 0, "embed_bwd: bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, S_, tokens, dx, dtable, B, L, W, vocab, seq_offs);
+    ILVLM_LAUNCH_CHECK("embed_bwd");
+    if (dpos) return batch_sum_impl(dx, dpos, nullptr, B, L, W, seq_offs, stream);
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_embed_fwd(const int64_t* tokens, const float* table, const float* pos, float* x, int B, int L, int W,
+                               int vocab, void* stream) {
+    return embed_fwd_impl(tokens, table, pos, x, B, L, W, vocab, nullptr, stream);
+}
+extern "C" int ilvlm_embed_bwd(const int64_t* tokens, const float* dx, float* dtable, float* dpos, int B, int L, int W,
+                               int vocab, void* stream) {
+    return embed_bwd_impl(tokens, dx, dtable, dpos, B, L, W, vocab, nullptr, stream);
+}
+extern "C" int ilvlm_embed_packed_fwd(const int64_t* tokens, const int32_t* seq_offs, const float* table, const float* pos,
+                                      float* x, int B, int L, int W, int vocab, void* stream) {
+    ILVLM_REQUIRE(seq_offs, "embed_packed_fwd: null seq_offs");
+    return embed_fwd_impl(tokens, table, pos, x, B, L, W, vocab, seq_offs, stream);
+}
+extern "C" int ilvlm_embed_packed_bwd(const int64_t* tokens, const int32_t* seq_offs, const float* dx, float* dtable,
+                                      float* dpos, int B, int L, int W, int vocab, void* stream) {
+    ILVLM_REQUIRE(seq_offs, "embed_packed_bwd: null seq_offs");
+    return embed_bwd_impl(tokens, dx, dtable, dpos, B, L, W, vocab, seq_offs, stream);
+}
+extern "C" int ilvlm_batch_sum(const float* x, float* out, float* out0, int B, int L, int W, void* stream) {
+    return batch_sum_impl(x, out, out0, B, L, W, nullptr, stream);
 }
 extern "C" int ilvlm_cls_rows(const float* cls, const float* pos, float* tokens, int B, int L, int W, void* stream) {
     ILVLM_REQUIRE(cls && pos && tokens && B > 0 && L > 0 && W > 0, "cls_rows: bad args");
@@ -393,37 +443,70 @@ extern "C" int ilvlm_patchify(const float* images, void* patches, int dtype, int
 }
 extern "C" int ilvlm_gather_rows(const float* x, const int64_t* idx, float* y, int B, int L, int W, void* stream) {
     ILVLM_REQUIRE(x && idx && y && B > 0 && L > 0 && W > 0, "gather_rows: bad args");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, S_, x, idx, y, B, L, W);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, S_, x, idx, y, B, L, W, (const int*)nullptr);
     ILVLM_LAUNCH_CHECK("gather_rows");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_gather_packed_rows(const float* x, const int64_t* idx, const int32_t* seq_offs, float* y, int B, int W,
+                                        void* stream) {
+    ILVLM_REQUIRE(x && idx && seq_offs && y && B > 0 && W > 0, "gather_packed_rows: bad args");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, S_, x, idx, y, B, 0, W, seq_offs);
+    ILVLM_LAUNCH_CHECK("gather_packed_rows");
     return ILVLM_OK;
 }
 extern "C" int ilvlm_scatter_rows(const float* dy, const int64_t* idx, float* dx, int B, int L, int W, void* stream) {
     ILVLM_REQUIRE(dy && idx && dx && B > 0 && L > 0 && W > 0, "scatter_rows: bad args");
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(B), dim3(256), 0, S_, dy, idx, dx, B, L, W);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(B), dim3(256), 0, S_, dy, idx, dx, B, L, W, (const int*)nullptr);
     ILVLM_LAUNCH_CHECK("scatter_rows");
     return ILVLM_OK;
 }
+extern "C" int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, const int32_t* seq_offs, float* dx, int B, int W,
+                                         void* stream) {
+    ILVLM_REQUIRE(dy && idx && seq_offs && dx && B > 0 && W > 0, "scatter_packed_rows: bad args");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(B), dim3(256), 0, S_, dy, idx, dx, B, 0, W, seq_offs);
+    ILVLM_LAUNCH_CHECK("scatter_packed_rows");
+    return ILVLM_OK;
+}
 
-extern "C" int ilvlm_fdt_pool_fwd(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T,
-                                  int C, float sqrt_d, float temperature, int pool, void* stream) {
+static int fdt_pool_fwd_impl(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T, int C,
+                             float sqrt_d, float temperature, int pool, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(scores && pooled && B > 0 && T > 0 && C > 0, "fdt_pool_fwd: bad args");
     ILVLM_REQUIRE(pool >= 0 && pool <= 2 && (pool != ILVLM_POOL_MAX || argmax), "fdt_pool_fwd: bad pool / missing argmax");
     ILVLM_REQUIRE(sqrt_d > 0.f && temperature != 0.f, "fdt_pool_fwd: bad scale");
     hipLaunchKernelGGL(fdt_pool_fwd_kernel, dim3(ceil_div(C, 256), B), dim3(256), 0, S_, scores, pad_mask, pooled, argmax, T,
-                       C, sqrt_d, temperature, pool);
+                       C, sqrt_d, temperature, pool, seq_offs);
     ILVLM_LAUNCH_CHECK("fdt_pool_fwd");
     return ILVLM_OK;
 }
-extern "C" int ilvlm_fdt_pool_bwd(const float* dpooled, const int* argmax, const float* pad_mask, void* dscores, int dtype,
-                                  int B, int T, int C, float sqrt_d, float temperature, int pool, void* stream) {
+static int fdt_pool_bwd_impl(const float* dpooled, const int* argmax, const float* pad_mask, void* dscores, int dtype, int B,
+                             int T, int C, float sqrt_d, float temperature, int pool, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(dpooled && dscores && B > 0 && T > 0 && C > 0, "fdt_pool_bwd: bad args");
     ILVLM_REQUIRE(pool >= 0 && pool <= 2 && (pool != ILVLM_POOL_MAX || argmax), "fdt_pool_bwd: bad pool / missing argmax");
     dim3 grid(ceil_div(C, 256), B);
-    if (dtype == ILVLM_BF16) hipLaunchKernelGGL(fdt_pool_bwd_kernel<bf16>, grid, dim3(256), 0, S_, dpooled, argmax, pad_mask, (bf16*)dscores, T, C, sqrt_d, temperature, pool);
-    else if (dtype == ILVLM_F32) hipLaunchKernelGGL(fdt_pool_bwd_kernel<float>, grid, dim3(256), 0, S_, dpooled, argmax, pad_mask, (float*)dscores, T, C, sqrt_d, temperature, pool);
+    if (dtype == ILVLM_BF16) hipLaunchKernelGGL(fdt_pool_bwd_kernel<bf16>, grid, dim3(256), 0, S_, dpooled, argmax, pad_mask, (bf16*)dscores, T, C, sqrt_d, temperature, pool, seq_offs);
+    else if (dtype == ILVLM_F32) hipLaunchKernelGGL(fdt_pool_bwd_kernel<float>, grid, dim3(256), 0, S_, dpooled, argmax, pad_mask, (float*)dscores, T, C, sqrt_d, temperature, pool, seq_offs);
     else ILVLM_FAIL(ILVLM_ERR_ARG, "fdt_pool_bwd: bad dtype %d", dtype);
     ILVLM_LAUNCH_CHECK("fdt_pool_bwd");
     return ILVLM_OK;
+}
+extern "C" int ilvlm_fdt_pool_fwd(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T,
+                                  int C, float sqrt_d, float temperature, int pool, void* stream) {
+    return fdt_pool_fwd_impl(scores, pad_mask, pooled, argmax, B, T, C, sqrt_d, temperature, pool, nullptr, stream);
+}
+extern "C" int ilvlm_fdt_pool_bwd(const float* dpooled, const int* argmax, const float* pad_mask, void* dscores, int dtype,
+                                  int B, int T, int C, float sqrt_d, float temperature, int pool, void* stream) {
+    return fdt_pool_bwd_impl(dpooled, argmax, pad_mask, dscores, dtype, B, T, C, sqrt_d, temperature, pool, nullptr, stream);
+}
+extern "C" int ilvlm_fdt_pool_packed_fwd(const float* scores, const int32_t* seq_offs, float* pooled, int* argmax, int B, int T,
+                                         int C, float sqrt_d, float temperature, int pool, void* stream) {
+    ILVLM_REQUIRE(seq_offs, "fdt_pool_packed_fwd: null seq_offs");
+    return fdt_pool_fwd_impl(scores, nullptr, pooled, argmax, B, T, C, sqrt_d, temperature, pool, seq_offs, stream);
+}
+extern "C" int ilvlm_fdt_pool_packed_bwd(const float* dpooled, const int* argmax, const int32_t* seq_offs, void* dscores,
+                                         int dtype, int B, int T, int C, float sqrt_d, float temperature, int pool,
+                                         void* stream) {
+    ILVLM_REQUIRE(seq_offs, "fdt_pool_packed_bwd: null seq_offs");
+    return fdt_pool_bwd_impl(dpooled, argmax, nullptr, dscores, dtype, B, T, C, sqrt_d, temperature, pool, seq_offs, stream);
 }
 
 extern "C" int ilvlm_sparsemax_fwd(const float* z, float* out, int rows, int cols, void* stream) {

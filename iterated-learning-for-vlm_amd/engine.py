@@ -165,7 +165,8 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ transformer block
-    def block_fwd(self, x_in, pre, B, L, H, causal, save):
+    def block_fwd(self, x_in, pre, B, L, H, causal, save, seq=None):
+        """seq: ops.PackedSeq when the rows are the valid tokens only (text tower of a training step)."""
         M, E = x_in.shape
         T = self.T
         Wf = self.Wf
@@ -174,7 +175,7 @@ class Engine:
         qkv = _empty((M, 3 * E), T, x_in)
         ops.gemm(h1, self._mat(pre + "attn.in_proj_weight"), qkv, bias=Wf[pre + "attn.in_proj_bias"])
         att = _empty((M, E), T, x_in); lse = _empty((B, H, L), torch.float32, x_in)
-        ops.attention_fwd(qkv, att, lse, B, L, H, causal)
+        ops.attention_fwd(qkv, att, lse, B, L, H, causal, seq)
         x_mid = _empty((M, E), torch.float32, x_in)
         ops.gemm(att, self._mat(pre + "attn.out_proj.weight"), x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
         h2 = _empty((M, E), T, x_in); mean2 = torch.empty_like(mean1); rstd2 = torch.empty_like(mean1)
@@ -186,7 +187,7 @@ class Engine:
         saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g) if save else None
         return x_out, saved
 
-    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal):
+    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None):
         """dx_f32: fp32 gradient of the block output; dx_lp: the same in T (None in fp32 mode).  Returns the pair
         for the block input."""
         x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
@@ -205,7 +206,7 @@ class Engine:
         # attention: x_mid = x_in + out_proj(attn(in_proj(h1)))
         da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias")
         dqkv = _empty((M, 3 * E), T, x_in)
-        ops.attention_bwd(da, qkv, att, lse, dqkv, B, L, H, causal)
+        ops.attention_bwd(da, qkv, att, lse, dqkv, B, L, H, causal, seq)
         dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias")
         din = _empty((M, E), torch.float32, x_in)
         din_lp = _empty((M, E), T, x_in) if lp else None
@@ -298,7 +299,9 @@ class Engine:
         ops.scatter_rows(dcls, idx, dx_stream, B, Lv, W)
 
     # ------------------------------------------------------------------ text tower
-    def text_fwd(self, tokens, save):
+    def text_fwd(self, tokens, save, seq=None):
+        """seq (ops.PackedSeq): run the tower on the valid tokens only -- rows [seq.offs[b], seq.offs[b+1]) of every text
+        tensor belong to caption b.  Without it every one of the B*ctx positions is computed, as the reference does."""
         cfg, Wf = self.cfg, self.Wf
         if tokens.dim() != 2 or tokens.shape[1] != cfg["ctx"] or tokens.dtype != torch.int64:
             raise RuntimeError("tokens must be int64 [B,%d], got %s %s" % (cfg["ctx"], tuple(tokens.shape), tokens.dtype))
@@ -306,13 +309,15 @@ class Engine:
         B, Lt = tokens.shape
         table = Wf["encode_text.token_embedding.weight"]
         Wt = table.shape[1]
-        x = _empty((B * Lt, Wt), torch.float32, table)
-        ops.embed_fwd(tokens, table, Wf["encode_text.positional_embedding"], x)
+        if seq is not None and (seq.B != B or seq.ctx != Lt):
+            raise RuntimeError("packed text rows: descriptor is for [%d,%d], tokens are [%d,%d]" % (seq.B, seq.ctx, B, Lt))
+        x = _empty((seq.rows if seq is not None else B * Lt, Wt), torch.float32, table)
+        ops.embed_fwd(tokens, table, Wf["encode_text.positional_embedding"], x, seq)
         blocks = []
         for i in range(cfg["t_layers"]):
-            x, s = self.block_fwd(x, "encode_text.transformer.resblocks.%d." % i, B, Lt, cfg["t_heads"], 1, save)
+            x, s = self.block_fwd(x, "encode_text.transformer.resblocks.%d." % i, B, Lt, cfg["t_heads"], 1, save, seq)
             blocks.append(s)
-        saved = dict(B=B, Lt=Lt, Wt=Wt, tokens=tokens, blocks=blocks) if save else None
+        saved = dict(B=B, Lt=Lt, Wt=Wt, tokens=tokens, blocks=blocks, seq=seq) if save else None
         return x, saved       # final residual stream BEFORE ln_final
 
     def text_bwd(self, saved, dx_f32, dx_lp):
@@ -320,13 +325,15 @@ class Engine:
         B, Lt = saved["B"], saved["Lt"]
         for i in reversed(range(cfg["t_layers"])):
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
-                                           Lt, cfg["t_heads"], 1)
+                                           Lt, cfg["t_heads"], 1, saved["seq"])
             self.m._sync("encode_text.transformer.resblocks.%d." % i)
         need_tab, need_pos = self.req["encode_text.token_embedding.weight"], self.req["encode_text.positional_embedding"]
         if need_tab:
             ops.embed_bwd(saved["tokens"], dx_f32, Gr["encode_text.token_embedding.weight"],
-                          Gr["encode_text.positional_embedding"] if need_pos else None)
+                          Gr["encode_text.positional_embedding"] if need_pos else None, saved["seq"])
         elif need_pos:
+            if saved["seq"] is not None:
+                raise NotImplementedError("packed text rows with a frozen token embedding and a trainable positional embedding")
             ops.batch_sum(dx_f32, Gr["encode_text.positional_embedding"], None, B, Lt, saved["Wt"])
 
     def text_words(self, x_final, save):
@@ -348,22 +355,22 @@ class Engine:
                           dx_lp=dx_lp)
         return dx, dx_lp
 
-    def text_pooled(self, x_final, tokens, B, Lt, save):
+    def text_pooled(self, x_final, tokens, B, Lt, save, seq=None):
         """ln_final at the EOT position (argmax of the ids, text_transformer.py:248) then text_projection."""
         Wf = self.Wf
         Wt = x_final.shape[1]
         idx = tokens.argmax(dim=-1)
         row = _empty((B, Wt), torch.float32, x_final)
-        ops.gather_rows(x_final, idx, row, B, Lt, Wt)
+        ops.gather_rows(x_final, idx, row, B, Lt, Wt, seq)
         feat = torch.empty_like(row); mean = _empty((B,), torch.float32, row); rstd = torch.empty_like(mean)
         ops.layernorm_fwd(row, Wf["encode_text.ln_final.weight"], Wf["encode_text.ln_final.bias"], feat, mean, rstd, B, Wt)
         w = Wf["encode_text.text_projection.weight"]
         out = _empty((B, w.shape[0]), torch.float32, row)
         ops.gemm(feat, w, out, bias=Wf["encode_text.text_projection.bias"])
-        return out, feat, ((idx, row, feat, mean, rstd) if save else None)
+        return out, feat, ((idx, row, feat, mean, rstd, seq) if save else None)
 
     def text_pooled_bwd(self, saved, dout, dx_stream, B, Lt):
-        idx, row, feat, mean, rstd = saved
+        idx, row, feat, mean, rstd, seq = saved
         Wf, Gr = self.Wf, self.Gr
         Wt = row.shape[1]
         w = Wf["encode_text.text_projection.weight"]
@@ -376,7 +383,7 @@ class Engine:
         drow = torch.empty_like(row)
         ops.layernorm_bwd(dfeat, row, mean, rstd, Wf["encode_text.ln_final.weight"], Gr["encode_text.ln_final.weight"],
                           Gr["encode_text.ln_final.bias"], B, Wt, dx_f32=drow)
-        ops.scatter_rows(drow, idx, dx_stream, B, Lt, Wt)
+        ops.scatter_rows(drow, idx, dx_stream, B, Lt, Wt, seq)
 
     # ------------------------------------------------------------------ FDT query model
     def qmap_fwd(self, ft, side, rows, ftdim, group, skip, save):
@@ -417,17 +424,18 @@ class Engine:
                           dx_f32=dwords)
         return dwords
 
-    def fdt_fwd(self, q, B, Tn, mask, temperature, save):
-        """codebook scores -> token pooling -> sparsemax/softmax -> weighted codebook sum (clip_fdt.py:113-154)."""
+    def fdt_fwd(self, q, B, Tn, mask, temperature, save, seq=None):
+        """codebook scores -> token pooling -> sparsemax/softmax -> weighted codebook sum (clip_fdt.py:113-154).
+        With seq (packed text rows) q holds the valid tokens only and the pad mask is implied by the row layout."""
         cfg, Wf = self.cfg, self.Wf
         sd = Wf["space_dict"]
         Cn, d = sd.shape
-        scores = _empty((B * Tn, Cn), torch.float32, q)
+        scores = _empty((q.shape[0], Cn), torch.float32, q)
         ops.gemm(q, self._mat("space_dict"), scores)
         pooled = _empty((B, Cn), torch.float32, q)
         pool = POOLS[cfg["pool"]]
         argmax = _empty((B, Cn), torch.int32, q) if pool == POOL_MAX else None
-        ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool)
+        ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool, seq)
         del scores
         att_w = torch.empty_like(pooled)
         if cfg["att_func"] == "sparsemax":
@@ -439,11 +447,11 @@ class Engine:
         # [B,C] x [C,d]: only (B/64)*(d/64) output tiles -> split the 4096-deep reduction over 8 workgroups each
         att_ft = torch.zeros((B, d), dtype=torch.float32, device=q.device)
         ops.gemm(att_w, sd, att_ft, trans_b=True, accumulate=True, split_k=8 if Cn >= 1024 else 1)
-        return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn) if save else None)
+        return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn, seq) if save else None)
 
     def fdt_bwd(self, saved, datt_ft):
         """Returns dq [B*Tn, d] in T; accumulates d space_dict."""
-        q, argmax, mask, att_w, temperature, B, Tn = saved
+        q, argmax, mask, att_w, temperature, B, Tn, seq = saved
         cfg, Wf, Gr, T = self.cfg, self.Wf, self.Gr, self.T
         sd = Wf["space_dict"]
         Cn, d = sd.shape
@@ -454,12 +462,13 @@ class Engine:
             ops.gemm(att_w, datt_ft, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True)   # att_w^T datt_ft
         dpooled = torch.empty_like(att_w)
         (ops.sparsemax_bwd if cfg["att_func"] == "sparsemax" else ops.softmax_bwd)(att_w, datt_w, dpooled)
-        dscores = _empty((B * Tn, Cn), T, q)
-        ops.fdt_pool_bwd(dpooled, argmax, mask, dscores, B, Tn, Cn, math.sqrt(d), temperature, POOLS[cfg["pool"]])
+        rows = q.shape[0]
+        dscores = _empty((rows, Cn), T, q)
+        ops.fdt_pool_bwd(dpooled, argmax, mask, dscores, B, Tn, Cn, math.sqrt(d), temperature, POOLS[cfg["pool"]], seq)
         if need_sd:
             ops.gemm(dscores, q, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True,
-                     split_k=ops.wgrad_split(Cn, d, B * Tn, 128 if T == torch.bfloat16 else 64))
-        dq = _empty((B * Tn, d), T, q)
+                     split_k=ops.wgrad_split(Cn, d, rows, 128 if T == torch.bfloat16 else 64))
+        dq = _empty((rows, d), T, q)
         ops.gemm(dscores, self._mat("space_dict"), dq, trans_b=True)
         return dq
 

@@ -59,6 +59,14 @@ SIGNATURES = {
     "ilvlm_clamp": [vp, f32, f32, i64, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
+    "ilvlm_embed_packed_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ilvlm_embed_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ilvlm_attention_packed_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "ilvlm_attention_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "ilvlm_gather_packed_rows": [vp, vp, vp, vp, i32, i32, vp],
+    "ilvlm_scatter_packed_rows": [vp, vp, vp, vp, i32, i32, vp],
+    "ilvlm_fdt_pool_packed_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp],
+    "ilvlm_fdt_pool_packed_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],
     "ilvlm_tokenizer_create": [C.c_char_p, i64, C.POINTER(vp)],
     "ilvlm_tokenizer_encode": [vp, C.POINTER(C.c_char_p), i32, i32, vp, vp, vp, vp],
     "ilvlm_tokenizer_destroy": [vp],

@@ -120,8 +120,9 @@ def gemm_set_variant(v):
 
 
 def rowsum_fusable(m, k):
-    """True when a weight-gradient GEMM with output rows m and reduction k can also produce the bias gradient."""
-    return k % 64 == 0 and m % 8 == 0 and m >= 8
+    """True when a weight-gradient GEMM with output rows m and reduction k can also produce the bias gradient (the
+    direct-to-LDS kernel takes any reduction length when both operands are K-strided, as they are in a weight gradient)."""
+    return m % 8 == 0 and m >= 8
 
 
 import os as _os
@@ -166,30 +167,69 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, rows, cols, dres=None
             "layernorm_bwd")
 
 
-def attention_fwd(qkv, out, lse, B, Lq, H, causal):
-    _chk(qkv, "attn.qkv", None, (B * Lq, 3 * 64 * H)); _chk(out, "attn.out", qkv.dtype, (B * Lq, 64 * H))
+class PackedSeq(object):
+    """Row layout of a packed text batch (include/ilvlm_hip.h, "packed text rows"): sequence b owns rows
+    [offs[b], offs[b+1]).  `lengths` is a host-side int sequence; the offsets live on the device as int32."""
+
+    def __init__(self, lengths, ctx, device):
+        lens = [int(v) for v in lengths]
+        if not lens or min(lens) < 1 or max(lens) > ctx:
+            raise RuntimeError("packed text rows: lengths must be in [1, %d]" % ctx)
+        offs = [0]
+        for v in lens:
+            offs.append(offs[-1] + v)
+        self.B, self.ctx, self.rows, self.cap = len(lens), int(ctx), offs[-1], max(lens)
+        self.lengths = lens
+        self.offs = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def attention_fwd(qkv, out, lse, B, Lq, H, causal, seq=None):
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(qkv, "attn.qkv", None, (rows, 3 * 64 * H)); _chk(out, "attn.out", qkv.dtype, (rows, 64 * H))
     _chk(lse, "attn.lse", torch.float32, (B, H, Lq))
+    if seq is not None:
+        L.check(L.load().ilvlm_attention_packed_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dt(qkv), B, Lq, seq.cap, H,
+                                                    int(causal), seq.offs.data_ptr(), _stream()), "attention_packed_fwd")
+        return
     L.check(L.load().ilvlm_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dt(qkv), B, Lq, H, int(causal),
                                          _stream()), "attention_fwd")
 
 
-def attention_bwd(dout, qkv, out, lse, dqkv, B, Lq, H, causal):
-    _chk(dout, "attn.dout", qkv.dtype, (B * Lq, 64 * H)); _chk(dqkv, "attn.dqkv", qkv.dtype, (B * Lq, 3 * 64 * H))
+def attention_bwd(dout, qkv, out, lse, dqkv, B, Lq, H, causal, seq=None):
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(dout, "attn.dout", qkv.dtype, (rows, 64 * H)); _chk(dqkv, "attn.dqkv", qkv.dtype, (rows, 3 * 64 * H))
+    if seq is not None:
+        L.check(L.load().ilvlm_attention_packed_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                    dqkv.data_ptr(), dt(qkv), B, Lq, seq.cap, H, int(causal),
+                                                    seq.offs.data_ptr(), _stream()), "attention_packed_bwd")
+        return
     L.check(L.load().ilvlm_attention_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
                                          dqkv.data_ptr(), dt(qkv), B, Lq, H, int(causal), _stream()), "attention_bwd")
 
 
-def embed_fwd(tokens, table, pos, x):
+def embed_fwd(tokens, table, pos, x, seq=None):
     B, Lq = tokens.shape
-    _chk(tokens, "embed.tokens", torch.int64); _chk(x, "embed.x", torch.float32, (B * Lq, table.shape[1]))
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(tokens, "embed.tokens", torch.int64); _chk(x, "embed.x", torch.float32, (rows, table.shape[1]))
     _chk(pos, "embed.pos", torch.float32, (Lq, table.shape[1]))
+    if seq is not None:
+        L.check(L.load().ilvlm_embed_packed_fwd(tokens.data_ptr(), seq.offs.data_ptr(), table.data_ptr(), pos.data_ptr(),
+                                                x.data_ptr(), B, Lq, table.shape[1], table.shape[0], _stream()),
+                "embed_packed_fwd")
+        return
     L.check(L.load().ilvlm_embed_fwd(tokens.data_ptr(), table.data_ptr(), pos.data_ptr(), x.data_ptr(), B, Lq,
                                      table.shape[1], table.shape[0], _stream()), "embed_fwd")
 
 
-def embed_bwd(tokens, dx, dtable, dpos):
+def embed_bwd(tokens, dx, dtable, dpos, seq=None):
     B, Lq = tokens.shape
-    _chk(dx, "embed.dx", torch.float32, (B * Lq, dtable.shape[1]))
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(dx, "embed.dx", torch.float32, (rows, dtable.shape[1]))
+    if seq is not None:
+        L.check(L.load().ilvlm_embed_packed_bwd(tokens.data_ptr(), seq.offs.data_ptr(), dx.data_ptr(), dtable.data_ptr(),
+                                                _p(dpos), B, Lq, dtable.shape[1], dtable.shape[0], _stream()),
+                "embed_packed_bwd")
+        return
     L.check(L.load().ilvlm_embed_bwd(tokens.data_ptr(), dx.data_ptr(), dtable.data_ptr(), _p(dpos), B, Lq,
                                      dtable.shape[1], dtable.shape[0], _stream()), "embed_bwd")
 
@@ -216,30 +256,50 @@ def batch_sum(x, out, out0, B, Lq, W):
     L.check(L.load().ilvlm_batch_sum(x.data_ptr(), out.data_ptr(), _p(out0), B, Lq, W, _stream()), "batch_sum")
 
 
-def gather_rows(x, idx, y, B, Lq, W):
-    _chk(x, "gather.x", torch.float32, (B * Lq, W)); _chk(y, "gather.y", torch.float32, (B, W))
+def gather_rows(x, idx, y, B, Lq, W, seq=None):
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(x, "gather.x", torch.float32, (rows, W)); _chk(y, "gather.y", torch.float32, (B, W))
     _chk(idx, "gather.idx", torch.int64, (B,))
+    if seq is not None:
+        L.check(L.load().ilvlm_gather_packed_rows(x.data_ptr(), idx.data_ptr(), seq.offs.data_ptr(), y.data_ptr(), B, W,
+                                                  _stream()), "gather_packed_rows")
+        return
     L.check(L.load().ilvlm_gather_rows(x.data_ptr(), idx.data_ptr(), y.data_ptr(), B, Lq, W, _stream()), "gather_rows")
 
 
-def scatter_rows(dy, idx, dx, B, Lq, W):
-    _chk(dx, "scatter.dx", torch.float32, (B * Lq, W)); _chk(dy, "scatter.dy", torch.float32, (B, W))
+def scatter_rows(dy, idx, dx, B, Lq, W, seq=None):
+    rows = seq.rows if seq is not None else B * Lq
+    _chk(dx, "scatter.dx", torch.float32, (rows, W)); _chk(dy, "scatter.dy", torch.float32, (B, W))
+    if seq is not None:
+        L.check(L.load().ilvlm_scatter_packed_rows(dy.data_ptr(), idx.data_ptr(), seq.offs.data_ptr(), dx.data_ptr(), B, W,
+                                                   _stream()), "scatter_packed_rows")
+        return
     L.check(L.load().ilvlm_scatter_rows(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, Lq, W, _stream()),
             "scatter_rows")
 
 
-def fdt_pool_fwd(scores, mask, pooled, argmax, B, T, Cn, sqrt_d, temp, pool):
-    _chk(scores, "fdt.scores", torch.float32, (B * T, Cn)); _chk(pooled, "fdt.pooled", torch.float32, (B, Cn))
+def fdt_pool_fwd(scores, mask, pooled, argmax, B, T, Cn, sqrt_d, temp, pool, seq=None):
+    rows = seq.rows if seq is not None else B * T
+    _chk(scores, "fdt.scores", torch.float32, (rows, Cn)); _chk(pooled, "fdt.pooled", torch.float32, (B, Cn))
     if mask is not None:
         _chk(mask, "fdt.mask", torch.float32, (B, T))
     if argmax is not None:
         _chk(argmax, "fdt.argmax", torch.int32, (B, Cn))
+    if seq is not None:
+        L.check(L.load().ilvlm_fdt_pool_packed_fwd(scores.data_ptr(), seq.offs.data_ptr(), pooled.data_ptr(), _p(argmax), B, T,
+                                                   Cn, sqrt_d, temp, pool, _stream()), "fdt_pool_packed_fwd")
+        return
     L.check(L.load().ilvlm_fdt_pool_fwd(scores.data_ptr(), _p(mask), pooled.data_ptr(), _p(argmax), B, T, Cn, sqrt_d,
                                         temp, pool, _stream()), "fdt_pool_fwd")
 
 
-def fdt_pool_bwd(dpooled, argmax, mask, dscores, B, T, Cn, sqrt_d, temp, pool):
-    _chk(dpooled, "fdt.dpooled", torch.float32, (B, Cn)); _chk(dscores, "fdt.dscores", None, (B * T, Cn))
+def fdt_pool_bwd(dpooled, argmax, mask, dscores, B, T, Cn, sqrt_d, temp, pool, seq=None):
+    rows = seq.rows if seq is not None else B * T
+    _chk(dpooled, "fdt.dpooled", torch.float32, (B, Cn)); _chk(dscores, "fdt.dscores", None, (rows, Cn))
+    if seq is not None:
+        L.check(L.load().ilvlm_fdt_pool_packed_bwd(dpooled.data_ptr(), _p(argmax), seq.offs.data_ptr(), dscores.data_ptr(),
+                                                   dt(dscores), B, T, Cn, sqrt_d, temp, pool, _stream()), "fdt_pool_packed_bwd")
+        return
     L.check(L.load().ilvlm_fdt_pool_bwd(dpooled.data_ptr(), _p(argmax), _p(mask), dscores.data_ptr(), dt(dscores), B, T,
                                         Cn, sqrt_d, temp, pool, _stream()), "fdt_pool_bwd")
 

@@ -18,8 +18,8 @@ class _StepFn(torch.autograd.Function):
     backward; their gradients are accumulated straight into the gradient arena by the kernels (returned as None)."""
 
     @staticmethod
-    def forward(ctx, model, images, tokens, pad_mask, *params):
-        li, lt, saved = model._forward_impl(images, tokens, pad_mask, True)
+    def forward(ctx, model, images, tokens, pad_mask, seq, *params):
+        li, lt, saved = model._forward_impl(images, tokens, pad_mask, True, seq)
         ctx.model, ctx.saved, ctx.n = model, saved, len(params)
         return li, lt
 
@@ -32,7 +32,16 @@ class _StepFn(torch.autograd.Function):
         dli = torch.zeros_like(li) if dli is None else dli
         dlt = torch.zeros_like(li) if dlt is None else dlt
         ctx.model._backward_impl(saved, dli, dlt)
-        return (None,) * (4 + ctx.n)
+        return (None,) * (5 + ctx.n)
+
+
+def _prefix_lengths(pad_mask):
+    """lengths of a host-side pad mask whose valid positions (0) form a prefix of every row; None otherwise"""
+    valid = (pad_mask == 0)
+    lens = valid.sum(1)
+    if bool((valid.int().cumprod(1).sum(1) == lens).all()) and int(lens.min()) >= 1:
+        return lens.tolist()
+    return None
 
 
 class ContrastiveBase(nn.Module):
@@ -47,17 +56,40 @@ class ContrastiveBase(nn.Module):
     def engine(self):
         return self._eng
 
-    def _text_inputs(self, texts, device):
-        """list[str] (tokenised here, as the reference does inside forward) or a (tokens, pad_mask) pair."""
-        if isinstance(texts, (tuple, list)) and len(texts) == 2 and torch.is_tensor(texts[0]):
-            tokens, pad_mask = texts
+    # Training steps run the text tower on the valid tokens only (include/ilvlm_hip.h, "packed text rows") whenever the
+    # caption lengths are known on the host without a device synchronisation: captions given as strings (tokenised here),
+    # (tokens, pad_mask) given as CPU tensors, or a third element -- the lengths (list / CPU tensor) or a ready
+    # ops.PackedSeq -- next to device tensors.  ILVLM_TEXT_PACK=0 or model.pack_text = False keeps every position.
+    pack_text = os.environ.get("ILVLM_TEXT_PACK", "1") != "0"
+
+    def _text_inputs(self, texts, device, want_seq=False):
+        """list[str] (tokenised here, as the reference does inside forward) or a (tokens, pad_mask[, lengths]) tuple.
+        Returns tokens, pad_mask on the device (+ the packed-row descriptor or None when want_seq)."""
+        lengths = None
+        if isinstance(texts, (tuple, list)) and len(texts) in (2, 3) and torch.is_tensor(texts[0]):
+            tokens, pad_mask = texts[0], texts[1]
+            if len(texts) == 3:
+                lengths = texts[2]
+            elif want_seq and not pad_mask.is_cuda:
+                lengths = _prefix_lengths(pad_mask)
         elif hasattr(texts, "out1"):
             tokens, pad_mask = texts.out1, texts.out2
+            if want_seq and not pad_mask.is_cuda:
+                lengths = _prefix_lengths(pad_mask)
         else:
-            tokens, pad_mask = self.encode_text.tokenize(texts, context_length=self.encode_text.context_length)
+            tokens, lengths, pad_mask = self.encode_text.tokenize(texts, context_length=self.encode_text.context_length,
+                                                                  return_length=True)
         tokens = tokens.to(device=device, dtype=torch.int64).contiguous()
         pad_mask = pad_mask.to(device=device, dtype=torch.float32).contiguous()
-        return tokens, pad_mask
+        if not want_seq:
+            return tokens, pad_mask
+        seq = None
+        if self.pack_text and lengths is not None and tokens.shape[1] <= 128:
+            if isinstance(lengths, ops.PackedSeq):
+                seq = lengths
+            else:
+                seq = ops.PackedSeq(lengths.tolist() if torch.is_tensor(lengths) else lengths, tokens.shape[1], device)
+        return tokens, pad_mask, seq
 
     def _run(self, images, texts):
         eng = self._eng
@@ -65,10 +97,11 @@ class ContrastiveBase(nn.Module):
         dev = eng.arena.P.device
         if not images.is_cuda:
             raise RuntimeError("images must be on the GPU (the solver calls image.cuda())")
-        tokens, pad_mask = self._text_inputs(texts, dev)
         params = [p for _, p in eng.arena.named]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _StepFn.apply(self, images, tokens, pad_mask, *params)
+            tokens, pad_mask, seq = self._text_inputs(texts, dev, want_seq=True)
+            return _StepFn.apply(self, images, tokens, pad_mask, seq, *params)
+        tokens, pad_mask = self._text_inputs(texts, dev)
         li, lt, _ = self._forward_impl(images, tokens, pad_mask, False)
         return li, lt
 

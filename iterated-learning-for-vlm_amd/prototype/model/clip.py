@@ -34,15 +34,15 @@ class CLIP(ContrastiveBase):
     def forward(self, images, texts):
         return self._run(images, texts)
 
-    def _forward_impl(self, images, tokens, pad_mask, save):
+    def _forward_impl(self, images, tokens, pad_mask, save, seq=None):
         e = self._eng
         B = images.shape[0]
         main, side = torch.cuda.current_stream(), e.side_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):              # text tower concurrently with the vision tower
-            xt, st = e.text_fwd(tokens, save)
+            xt, st = e.text_fwd(tokens, save, seq)
             Lt = tokens.shape[1]
-            txt, _, spt = e.text_pooled(xt, tokens, B, Lt, save)
+            txt, _, spt = e.text_pooled(xt, tokens, B, Lt, save, seq)
         xv, sv = e.vision_fwd(images, save)
         Lv = xv.shape[0] // B
         img, _, spv = e.vision_pooled(xv, B, Lv, save)

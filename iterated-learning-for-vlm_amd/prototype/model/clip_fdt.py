@@ -76,17 +76,17 @@ class Clip_FDT(ContrastiveBase):
         li, lt = self._run(images, texts)
         return (li, lt), (self.space_dict, self.space_dict)
 
-    def _forward_impl(self, images, tokens, pad_mask, save):
+    def _forward_impl(self, images, tokens, pad_mask, save, seq=None):
         e = self._eng
         B = images.shape[0]
         main, side = torch.cuda.current_stream(), e.side_stream
         side.wait_stream(main)                     # parameters / shadow / inputs produced on the main stream
-        with torch.cuda.stream(side):              # text tower + text query head
-            xt, st = e.text_fwd(tokens, save)
+        with torch.cuda.stream(side):              # text tower + text query head (on the valid tokens only with seq)
+            xt, st = e.text_fwd(tokens, save, seq)
             Lt, Wt = tokens.shape[1], xt.shape[1]
             words, sw = e.text_words(xt, save)
-            qt, sqt = e.qmap_fwd(words, "txt_query_model.", B * Lt, Wt, 0, 0, save)
-            _, ftt, sft = e.fdt_fwd(qt, B, Lt, pad_mask, self.txt_query_model.temperature, save)
+            qt, sqt = e.qmap_fwd(words, "txt_query_model.", xt.shape[0], Wt, 0, 0, save)
+            _, ftt, sft = e.fdt_fwd(qt, B, Lt, pad_mask, self.txt_query_model.temperature, save, seq)
         xv, sv = e.vision_fwd(images, save)        # vision tower + image query head, concurrently on the main stream
         Lv, W = xv.shape[0] // B, xv.shape[1]
         qi, sqi = e.qmap_fwd(xv, "img_query_model.", B * (Lv - 1), W, Lv - 1, 1, save)

@@ -72,7 +72,9 @@ class SyntheticPairs:
             tok[b, 1:n - 1] = torch.randint(0, 49406, (n - 2,), generator=g)
             tok[b, n - 1] = 49408
             pad[b, :n] = 0
-        self.text = (tok.to(device), pad.to(device))
+        # caption lengths travel with the batch as host metadata (what a tokenising loader knows), so the text tower runs on
+        # the valid tokens only
+        self.text = (tok.to(device), pad.to(device), [int(n) for n in lens])
 
     def set_epoch(self, epoch):
         pass

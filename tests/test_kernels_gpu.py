@@ -52,7 +52,7 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1
 GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
-@pytest.mark.parametrize("variant", [5, 7])
+@pytest.mark.parametrize("variant", [5, 6, 7])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 392, 256), (136, 2304, 768), (8, 8, 128)])
 def test_gemm_direct_to_lds_variants(variant, ta, tb, M, N, K):
@@ -500,3 +500,113 @@ def test_small_elementwise_kernels():
     z = dev(torch.tensor([2.0, 3.5, 7.0]))
     ops.clamp_(z, 3, 6)
     assert z.cpu().tolist() == [3.0, 3.5, 6.0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# packed text rows (include/ilvlm_hip.h): the packed entry points against the dense ones, sequence by sequence
+# ---------------------------------------------------------------------------------------------------------------------
+PACK_LENS = [[77, 8, 41, 16, 17, 33, 2, 64], [5, 1, 3], [24, 24], [80, 79, 1, 48]]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("lens", PACK_LENS, ids=[str(len(l)) + "seq" for l in PACK_LENS])
+@pytest.mark.parametrize("causal", [1, 0])
+def test_packed_attention_matches_dense(dtype, lens, causal):
+    ops = _ops()
+    H, ctx = 2, (80 if max(lens) > 77 else 77)
+    B, E = len(lens), 64 * H
+    seq = ops.PackedSeq(lens, ctx, "cuda")
+    qkv = rnd(seq.rows, 3 * E, seed=3).to(dtype).cuda()
+    dout = rnd(seq.rows, E, seed=4).to(dtype).cuda()
+    out = torch.full((seq.rows, E), float("nan"), device="cuda", dtype=dtype)
+    lse = torch.full((B, H, ctx), float("nan"), device="cuda")
+    dqkv = torch.full((seq.rows, 3 * E), float("nan"), device="cuda", dtype=dtype)
+    ops.attention_fwd(qkv, out, lse, B, ctx, H, causal, seq)
+    ops.attention_bwd(dout, qkv, out, lse, dqkv, B, ctx, H, causal, seq)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any() and not torch.isnan(dqkv.float()).any()     # every packed row written
+    off = 0
+    for b, n in enumerate(lens):
+        q1 = qkv[off:off + n].contiguous()
+        o1 = torch.empty(n, E, device="cuda", dtype=dtype)
+        l1 = torch.empty(1, H, n, device="cuda")
+        d1 = torch.empty(n, 3 * E, device="cuda", dtype=dtype)
+        ops.attention_fwd(q1, o1, l1, 1, n, H, causal)
+        ops.attention_bwd(dout[off:off + n].contiguous(), q1, o1, l1, d1, 1, n, H, causal)
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        assert rel(out[off:off + n], o1.float().cpu()) < tol
+        assert rel(lse[b, :, :n], l1[0].cpu()) < 1e-6
+        assert rel(dqkv[off:off + n], d1.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
+        off += n
+
+
+def test_packed_embedding_pooling_and_row_gather():
+    ops = _ops()
+    lens, ctx, W, V, Cn = [7, 24, 1, 13, 24], 24, 64, 500, 300
+    B = len(lens)
+    seq = ops.PackedSeq(lens, ctx, "cuda")
+    gen = torch.Generator().manual_seed(5)
+    tok = torch.randint(1, V, (B, ctx), generator=gen)
+    mask = torch.full((B, ctx), float("-inf"))
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+        mask[b, :n] = 0
+    rows = torch.cat([torch.arange(n) + b * ctx for b, n in enumerate(lens)])
+    table, pos = rnd(V, W, seed=1), rnd(ctx, W, seed=2)
+    xd = torch.empty(B * ctx, W, device="cuda"); xp = torch.full((seq.rows, W), float("nan"), device="cuda")
+    ops.embed_fwd(dev(tok), dev(table), dev(pos), xd)
+    ops.embed_fwd(dev(tok), dev(table), dev(pos), xp, seq)
+    assert torch.equal(xp.cpu(), xd.cpu()[rows])
+    # backward: dense gradient is zero on the padded rows, as in the step
+    dxd = rnd(B * ctx, W, seed=3)
+    keep = torch.zeros(B * ctx, 1); keep[rows] = 1
+    dxd = dxd * keep
+    dtd, dpd = torch.zeros(V, W, device="cuda"), torch.zeros(ctx, W, device="cuda")
+    dtp, dpp = torch.zeros(V, W, device="cuda"), torch.zeros(ctx, W, device="cuda")
+    ops.embed_bwd(dev(tok), dev(dxd), dtd, dpd)
+    ops.embed_bwd(dev(tok), dev(dxd[rows].contiguous()), dtp, dpp, seq)
+    assert rel(dtp, dtd.cpu()) < 1e-6 and rel(dpp, dpd.cpu()) < 1e-6
+    # EOT-style row gather / scatter
+    idx = torch.tensor([n - 1 for n in lens])
+    yd, yp = torch.empty(B, W, device="cuda"), torch.empty(B, W, device="cuda")
+    ops.gather_rows(xd, dev(idx), yd, B, ctx, W)
+    ops.gather_rows(xp, dev(idx), yp, B, ctx, W, seq)
+    assert torch.equal(yd.cpu(), yp.cpu())
+    sd_, sp_ = torch.zeros(B * ctx, W, device="cuda"), torch.zeros(seq.rows, W, device="cuda")
+    ops.scatter_rows(yd, dev(idx), sd_, B, ctx, W)
+    ops.scatter_rows(yd, dev(idx), sp_, B, ctx, W, seq)
+    assert torch.equal(sd_.cpu()[rows], sp_.cpu())
+    # FDT pooling: scores of the padded positions are arbitrary in the dense form (they are multiplied by zero)
+    sc = rnd(B * ctx, Cn, seed=7)
+    sc[:, :40] -= 3.0          # some codes negative everywhere: the zero of a masked position wins the maximum
+    for pool in (0, 1, 2):
+        pd, pp = torch.empty(B, Cn, device="cuda"), torch.empty(B, Cn, device="cuda")
+        ad = torch.empty(B, Cn, device="cuda", dtype=torch.int32); ap = torch.empty_like(ad)
+        ops.fdt_pool_fwd(dev(sc), dev(mask), pd, ad if pool == 0 else None, B, ctx, Cn, 8.0, 2.0, pool)
+        ops.fdt_pool_fwd(dev(sc[rows].contiguous()), None, pp, ap if pool == 0 else None, B, ctx, Cn, 8.0, 2.0, pool, seq)
+        assert torch.equal(pd.cpu(), pp.cpu())
+        if pool == 0:
+            assert torch.equal(ad.cpu(), ap.cpu())
+        dp = rnd(B, Cn, seed=9)
+        dsd = torch.empty(B * ctx, Cn, device="cuda"); dsp = torch.full((seq.rows, Cn), float("nan"), device="cuda")
+        ops.fdt_pool_bwd(dev(dp), ad if pool == 0 else None, dev(mask), dsd, B, ctx, Cn, 8.0, 2.0, pool)
+        ops.fdt_pool_bwd(dev(dp), ap if pool == 0 else None, None, dsp, B, ctx, Cn, 8.0, 2.0, pool, seq)
+        assert torch.equal(dsd.cpu()[rows], dsp.cpu())
+        assert float(dsd.cpu()[keep[:, 0] == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("K", [10873, 77, 4097])
+def test_weight_gradient_gemm_with_ragged_reduction(K):
+    """both operands K-strided: the reduction length need not be a multiple of the K-tile (packed text rows)"""
+    ops = _ops()
+    M, N = 256, 192
+    a, b = rnd(K, M, seed=1).to(torch.bfloat16), rnd(K, N, seed=2).to(torch.bfloat16)
+    # neighbours in memory that must NOT leak into the sum: allocate the operands inside larger poisoned buffers
+    abuf = torch.full((K + 70, M), float("nan"), dtype=torch.bfloat16, device="cuda"); abuf[:K] = a.cuda()
+    bbuf = torch.full((K + 70, N), float("nan"), dtype=torch.bfloat16, device="cuda"); bbuf[:K] = b.cuda()
+    out = torch.zeros(M, N, device="cuda")
+    bias = torch.zeros(M, device="cuda")
+    ops.gemm(abuf[:K], bbuf[:K], out, trans_a=True, trans_b=True, accumulate=True, split_k=5, a_rowsum=bias)
+    ref = a.float().t() @ b.float()
+    assert rel(out, ref) < 2e-3
+    assert rel(bias, a.float().sum(0)) < 2e-3

@@ -63,13 +63,17 @@ def grad_report(model, g, prefix):
     return worst, worst_name, cos
 
 
+@pytest.mark.parametrize("pack", [True, False], ids=["packed-text-rows", "all-positions"])
 @pytest.mark.parametrize("ck", list(CFG))
 @pytest.mark.parametrize("v", FDT_VARIANTS, ids=variant_key)
-def test_fdt_step_fp32_matches_reference(golden_dir, ck, v):
+def test_fdt_step_fp32_matches_reference(golden_dir, ck, v, pack):
+    """pack=True: the captions' lengths are known on the host (CPU pad mask), so the text tower runs on the valid tokens
+    only; pack=False computes all ctx positions as the reference does.  Same goldens, same tolerances."""
     from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
     g = np.load(os.path.join(golden_dir, "g1_fdt_step_%s.npz" % ck))
     vk = variant_key(v)
     model = build(ck, v, "fp32", logit_scale=v[3])
+    model.pack_text = pack
     img = torch.from_numpy(g["images"]).cuda()
     tok, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["pad_mask"])
     (li, lt), (sd, _) = model(img, (tok, mask))
@@ -140,13 +144,15 @@ def test_fdt_step_bf16_within_tolerance(golden_dir, ck, v, tol):
         assert cos > 0.98, "bf16 gradient direction cos=%.5f (worst %s %.3e)" % (cos, name, worst)
 
 
+@pytest.mark.parametrize("pack", [True, False], ids=["packed-text-rows", "all-positions"])
 @pytest.mark.parametrize("ck", list(CFG))
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-2)])
-def test_clip_baseline_step(golden_dir, ck, precision, tol):
+def test_clip_baseline_step(golden_dir, ck, precision, tol, pack):
     from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
     g = np.load(os.path.join(golden_dir, "g2_clip_step_%s.npz" % ck))
     c = CFG[ck]
     model = build(ck, None, precision)
+    model.pack_text = pack
     img = torch.from_numpy(det_images(c["batch"], c["res"], SEED)).cuda()
     tok, mask = det_tokens(c["batch"], c["ctx"], SEED)
     li, lt = model(img, (torch.from_numpy(tok), torch.from_numpy(mask)))
@@ -238,3 +244,44 @@ def test_vit_l14_fdt_real_size_forward_matches_oracle():
     torch.cuda.synchronize()
     assert relerr(li, o["logits_i"].numpy()) < 1e-2 and relerr(lt, o["logits_t"].numpy()) < 1e-2
     assert torch.isfinite(loss) and float(model.visual.transformer.resblocks[0].mlp.c_fc.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_packed_text_rows_equal_all_positions(golden_dir, precision):
+    """Same step with the text tower on the valid tokens only vs on all ctx positions: logits, loss and every gradient must
+    agree to rounding (fp32: different atomic summation orders only), incl. max / mean / sum pooling and a caption that fills
+    the context.  Lengths come from a CPU pad mask, an explicit list, or a ready PackedSeq."""
+    from ilvlm_amd import ops
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    g = np.load(os.path.join(golden_dir, "g1_fdt_step_a.npz"))
+    img = torch.from_numpy(g["images"]).cuda()
+    tok, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["pad_mask"])
+    lens = (mask == 0).sum(1).tolist()
+    for v in (FDT_VARIANTS[0], FDT_VARIANTS[2], FDT_VARIANTS[3]):
+        outs = []
+        for how in ("dense", "cpu-mask", "lengths", "packedseq"):
+            model = build("a", v, precision, logit_scale=v[3])
+            if how == "dense":
+                texts = (tok.cuda(), mask.cuda())                 # device tensors without lengths: all positions
+            elif how == "cpu-mask":
+                texts = (tok, mask)
+            elif how == "lengths":
+                texts = (tok.cuda(), mask.cuda(), lens)
+            else:
+                texts = (tok.cuda(), mask.cuda(), ops.PackedSeq(lens, tok.shape[1], "cuda"))
+            (li, lt), _ = model(img, texts)
+            loss, _ = ClipInfoCELoss()(li, lt)
+            model.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((li.detach().float().cpu(), loss.item(), {n: p.grad.detach().float().cpu().clone()
+                                                                   for n, p in model.named_parameters() if p.grad is not None}))
+        tol = 2e-5 if precision == "fp32" else 2e-2
+        ref = outs[0]
+        for o in outs[1:]:
+            assert relerr(o[0], ref[0].numpy()) < tol
+            assert abs(o[1] - ref[1]) < tol * abs(ref[1])
+            for n, gr in ref[2].items():
+                scale = max(float(gr.abs().max()), 1e-12)
+                err = float((o[2][n] - gr).abs().max()) / scale
+                assert err < (1e-4 if precision == "fp32" else 8e-2) or float((o[2][n] - gr).abs().max()) < 1e-7, (variant_key(v), n, err)
