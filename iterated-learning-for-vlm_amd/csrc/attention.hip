@@ -196,6 +196,19 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
     const int L = seq_offs ? seq_offs[b + 1] - seq_offs[b] : Lmax;
     const bf16* base = qkv + row0 * rs + h * HD;
     const bf16* vbase = base + 2 * E;
+    // V is only ever an MFMA operand with the head dimension contiguous: its fragments come straight from global memory,
+    // requested before the staging loop so their latency hides behind it and the barrier
+    // (up to 4 tiles = 32 registers; beyond that the occupancy lost costs more than the latency hidden, so longer sequences
+    // fetch the fragments where they are used)
+    constexpr bool PREV = NT <= 4;
+    bf16x8 vf[PREV ? NT : 1][2];
+    if (PREV) {
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            vf[PREV ? kt : 0][0] = frag_global(vbase, rs, kt * 16 + (lane & 15), L, 0, lane);
+            vf[PREV ? kt : 0][1] = frag_global(vbase, rs, kt * 16 + (lane & 15), L, 32, lane);
+        }
+    }
     stage_rows<ROWS, NTH>(Qs, base, rs, L, 0.125f, tid);
     stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
     const bf16* dob = dout + row0 * E + h * HD;
@@ -237,12 +250,12 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
         for (int kt = 0; kt < NTE; ++kt) {
             ds[kt] = (bf16x4){0, 0, 0, 0};
             if (kt < NT && kt < nkt) {
-                const int krow = kt * 16 + c16;
                 f32x4 st = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
                 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 0, lane), qb0, st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16, 32, lane), qb1, st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_global(vbase, rs, krow, L, 0, lane), db0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_global(vbase, rs, krow, L, 32, lane), db1, dp, 0, 0, 0);
+                const int krow = kt * 16 + c16;
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PREV ? vf[PREV ? kt : 0][0] : frag_global(vbase, rs, krow, L, 0, lane), db0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PREV ? vf[PREV ? kt : 0][1] : frag_global(vbase, rs, krow, L, 32, lane), db1, dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
@@ -269,7 +282,15 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
     {   // ---- pass B: dK, dV of key tile `wave`.  Plain products: lane (g, c16 = key) holds queries 16 qt + 4 g + r.
         const int key = wave * 16 + c16;
         const bf16x8 kb0 = frag_k(Ks, LDH, wave * 16, 0, lane), kb1 = frag_k(Ks, LDH, wave * 16, 32, lane);
-        const bf16x8 vb0 = frag_global(vbase, rs, key, L, 0, lane), vb1 = frag_global(vbase, rs, key, L, 32, lane);
+        bf16x8 vb0, vb1;                                // this wave's own key tile
+        if (PREV) {                                     // wave-uniform select, no register indexing
+            vb0 = vf[0][0]; vb1 = vf[0][1];
+#pragma unroll
+            for (int kt = 1; kt < NT; ++kt)
+                if (kt == wave) { vb0 = vf[PREV ? kt : 0][0]; vb1 = vf[PREV ? kt : 0][1]; }
+        } else {
+            vb0 = frag_global(vbase, rs, key, L, 0, lane); vb1 = frag_global(vbase, rs, key, L, 32, lane);
+        }
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0, 0, 0, 0}; dv[dt] = (f32x4){0, 0, 0, 0}; }
