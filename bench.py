@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--all-text-positions", action="store_true",
                     help="compute all 77 positions of every caption as the reference does; default: the text tower runs on the "
                          "valid tokens only (rows behind <|endoftext|> never reach the loss; same logits and gradients)")
+    ap.add_argument("--phase-times", action="store_true", help="diagnostic: GPU time between the phase boundaries of a step")
     ap.add_argument("--serial-towers", action="store_true",
                     help="run both towers on one stream (used for per-kernel profiles; the headline run overlaps them)")
     return ap.parse_args()
@@ -247,6 +248,18 @@ def main():
         if not args.no_roofline and args.precision == "bf16":
             for _ in range(2):
                 one_step()
+    if args.phase_times and rank == 0:
+        model._phase_marks = []
+        for _ in range(5):
+            one_step()
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); model._phase_marks.append(("optimizer_done", ev))
+        torch.cuda.synchronize()
+        marks, model._phase_marks = model._phase_marks, None
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            acc.setdefault("%s -> %s" % (n0, n1), []).append(e0.elapsed_time(e1))
+        for k, v in acc.items():
+            print("phase %-40s %7.3f ms" % (k, sum(v) / len(v)), file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "vitb32":
         cpu = cpu_baseline()

@@ -66,6 +66,7 @@ class CLIP(ContrastiveBase):
                 dxt_lp = torch.empty(s["xt"], dtype=e.T, device=dli.device)
                 ops.cast_f32(dxt, dxt_lp)
             e.text_bwd(s["text"], dxt, dxt_lp)
+            e.join_wgrad()
             self._sync("text_done")
         dxv = torch.zeros(s["xv"], dtype=torch.float32, device=dli.device)
         e.vision_pooled_bwd(s["pv"], d_img, dxv, s["B"], s["Lv"])
@@ -74,6 +75,7 @@ class CLIP(ContrastiveBase):
             dxv_lp = torch.empty(s["xv"], dtype=e.T, device=dli.device)
             ops.cast_f32(dxv, dxv_lp)
         e.vision_bwd(s["vision"], dxv, dxv_lp)
+        e.join_wgrad()
         main.wait_stream(side)
         self._sync("all_done")
 

@@ -76,9 +76,18 @@ class Clip_FDT(ContrastiveBase):
         li, lt = self._run(images, texts)
         return (li, lt), (self.space_dict, self.space_dict)
 
+    def _mark(self, name):
+        """diagnostic (bench.py --phase-times): an event on the current stream at a phase boundary of the step"""
+        marks = getattr(self, "_phase_marks", None)
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+
     def _forward_impl(self, images, tokens, pad_mask, save, seq=None):
         e = self._eng
         B = images.shape[0]
+        self._mark("step_begin")
         main, side = torch.cuda.current_stream(), e.side_stream
         side.wait_stream(main)                     # parameters / shadow / inputs produced on the main stream
         with torch.cuda.stream(side):              # text tower + text query head (on the valid tokens only with seq)
@@ -92,14 +101,18 @@ class Clip_FDT(ContrastiveBase):
         qi, sqi = e.qmap_fwd(xv, "img_query_model.", B * (Lv - 1), W, Lv - 1, 1, save)
         _, fti, sfi = e.fdt_fwd(qi, B, Lv - 1, None, self.img_query_model.temperature, save)
         main.wait_stream(side)
+        self._mark("towers_fwd_done")
         li, lt, sh = e.head_fwd(fti, ftt, 1e-10, 1e-10, save)
+        self._mark("head_fwd_done")
         saved = dict(vision=sv, text=st, words=sw, qi=sqi, fi=sfi, qt=sqt, ft=sft, head=sh, B=B, Lv=Lv, W=W) if save else None
         return li, lt, saved
 
     def _backward_impl(self, s, dli, dlt):
         e = self._eng
         main, side = torch.cuda.current_stream(), e.side_stream
+        self._mark("loss_done")
         d_fti, d_ftt = e.head_bwd(s["head"], dli, dlt)
+        self._mark("head_bwd_done")
         d_ftt.record_stream(side)                  # allocated on the main stream, consumed on the side stream
         side.wait_stream(main)
         with torch.cuda.stream(side):              # text side
@@ -107,6 +120,7 @@ class Clip_FDT(ContrastiveBase):
             dwords = e.qmap_bwd(s["qt"], "txt_query_model.", dqt)
             dxt, dxt_lp = e.text_words_bwd(s["words"], dwords)
             e.text_bwd(s["text"], dxt, dxt_lp)
+            e.join_wgrad()
             self._sync("text_done")                # gradient all-reduce of the text ranges waits on this stream
         dqi = e.fdt_bwd(s["fi"], d_fti)            # image side, concurrently
         B, Lv, W = s["B"], s["Lv"], s["W"]
@@ -120,7 +134,9 @@ class Clip_FDT(ContrastiveBase):
             dxv_lp.view(B, Lv, W)[:, 0].zero_()
         e.qmap_bwd(s["qi"], "img_query_model.", dqi, dxv, dxv_lp)
         e.vision_bwd(s["vision"], dxv, dxv_lp)
+        e.join_wgrad()
         main.wait_stream(side)
+        self._mark("towers_bwd_done")
         self._sync("all_done")
 
     # ---------------------------------------------------------------- evaluation-time API (no gradient)
