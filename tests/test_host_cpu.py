@@ -135,3 +135,29 @@ def test_tokenizer_matches_reference(golden_dir):
     assert tt.tokenizer.decode(tok[0][1:6].tolist()).strip() == "a photo of a cat"
     wrapped = tt.wrap_tokenize(g["captions"][:2])
     assert wrapped.out1.shape == (2, 77)
+
+
+def test_async_checkpoint_writer_roundtrip_and_errors(tmp_path):
+    """the writer thread produces torch.load-compatible files of the state as it was at save() time, writes atomically
+    (tmp + rename) and reports failures at wait()"""
+    from ilvlm_amd.solver import AsyncCheckpointWriter
+    w = AsyncCheckpointWriter()
+    t = torch.arange(12, dtype=torch.float32).view(3, 4)
+    state = {"model": {"module.a": t, "module.b": torch.ones(2)}, "optimizer": {"state": {0: {"exp_avg": t * 2}},
+             "param_groups": [{"lr": 0.1, "params": [0]}]}, "last_iter": 7}
+    p1, p2 = str(tmp_path / "ckpt_7.pth.tar"), str(tmp_path / "k" / "ckpt_7.pth.tar")
+    os.makedirs(os.path.dirname(p2))
+    w.save(state, [p1, p2])
+    t.add_(100)                       # later training steps must not leak into the snapshot
+    w.wait()
+    for p in (p1, p2):
+        ck = torch.load(p, map_location="cpu", weights_only=False)
+        assert ck["last_iter"] == 7 and set(ck) == {"model", "optimizer", "last_iter"}
+        assert torch.equal(ck["model"]["module.a"], torch.arange(12, dtype=torch.float32).view(3, 4))
+        assert torch.equal(ck["optimizer"]["state"][0]["exp_avg"], torch.arange(12, dtype=torch.float32).view(3, 4) * 2)
+        assert ck["optimizer"]["param_groups"] == [{"lr": 0.1, "params": [0]}]
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    w.save(state, [str(tmp_path / "missing_dir" / "x.pth.tar")])
+    with pytest.raises(RuntimeError):
+        w.wait()
+    w.wait()                          # error is reported once
