@@ -88,6 +88,72 @@ class SyntheticPairs:
         return self
 
 
+class DevicePrefetcher:
+    """Feeds the step from any iterable of (image [B,3,H,W] CPU tensor, captions list[str]) batches -- what the
+    reference's loader yields (prototype/data/clip_dataset_wsd.py:158-240) -- one batch ahead of the GPU
+    (SURVEY.md 8f-1/2): a worker thread tokenises the captions with the C++ BPE (the reference does it in Python inside
+    forward(), on the training thread), pins the image batch and copies it to the device on its own stream; the
+    consumer receives (image_cuda, (tokens, pad_mask, lengths)), i.e. the text tower can run on the valid tokens and
+    the H2D copy / tokenisation of batch i+1 overlap the step on batch i.  Already-tokenised text passes through."""
+
+    def __init__(self, loader, tokenize, device, depth=2):
+        self.loader, self.tokenize, self.device, self.depth = loader, tokenize, torch.device(device), depth
+        self.dataloader = self
+        self.num_batches = getattr(loader, "num_batches", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def set_epoch(self, epoch):
+        if hasattr(self.loader, "set_epoch"):
+            self.loader.set_epoch(epoch)
+
+    def _stage(self, image, text, stream):
+        cuda = self.device.type == "cuda"
+        if isinstance(text, (list, tuple)) and text and isinstance(text[0], str):
+            tokens, lengths, pad = self.tokenize(list(text), return_length=True)
+            text = (tokens, pad, lengths.tolist())
+        if cuda:
+            with torch.cuda.stream(stream):
+                image = (image if image.is_pinned() else image.pin_memory()).to(self.device, non_blocking=True)
+                if isinstance(text, tuple) and torch.is_tensor(text[0]):
+                    text = tuple(t.pin_memory().to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in text)
+                done = torch.cuda.Event()
+                done.record(stream)
+            return image, text, done
+        return image, text, None
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        stop = object()
+
+        def work():
+            try:
+                for image, text in self.loader:
+                    q.put(self._stage(image, text, stream))
+                q.put(stop)
+            except Exception as e:          # re-raised in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=work, name="ilvlm-prefetch", daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, Exception):
+                raise item
+            image, text, done = item
+            if done is not None:
+                torch.cuda.current_stream(self.device).wait_event(done)     # order the step after the copies
+                image.record_stream(torch.cuda.current_stream(self.device))
+            yield image, text
+        t.join()
+
+
 class AsyncCheckpointWriter:
     """Checkpoint I/O off the training thread (the reference blocks every rank in torch.save + barrier,
     train_solver.py:521-543).  save() snapshots the state on the device (a device-to-device copy, ordered on the training
@@ -232,6 +298,10 @@ class ClsSolver:
 
     def build_data(self):
         if self.train_data is not None:
+            if os.environ.get("ILVLM_PREFETCH", "1") == "1" and not isinstance(self.train_data, (SyntheticPairs, DevicePrefetcher)):
+                self.train_data = DevicePrefetcher(getattr(self.train_data, "dataloader", self.train_data),
+                                                   self.model.module.encode_text.tokenize,
+                                                   torch.device("cuda", self.local_rank))
             return
         tc = self.config.data.train
         if getattr(self.args, "synthetic", False) or tc.get("synthetic", False):
@@ -340,14 +410,16 @@ class ClsSolver:
         self.topk = 5
         pf = cfg.saver.print_freq
         meters = {k: DeviceMeter(pf, dev) for k in ("loss", "top1", "top5")}
-        each_epoch = getattr(self.train_data.dataloader, "num_batches", None) or len(self.train_data.dataloader)
+        loader = getattr(self.train_data, "dataloader", self.train_data)     # the reference's wrapper or a plain iterable
+        each_epoch = getattr(loader, "num_batches", None) or len(loader)
         total_step = cfg.data.train.epoch * each_epoch
         start_step = curr_step = self.state["last_iter"]
         end = time.time()
         losses = []
         for epoch_id in range(cfg.data.train.epoch):
-            self.train_data.set_epoch(epoch_id)
-            for image, text in self.train_data.dataloader:
+            if hasattr(self.train_data, "set_epoch"):
+                self.train_data.set_epoch(epoch_id)
+            for image, text in loader:
                 curr_step += 1
                 loss, p1, p5 = self.train_step(image, text, curr_step)
                 meters["loss"].update(loss); meters["top1"].update(p1); meters["top5"].update(p5)

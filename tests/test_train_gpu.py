@@ -144,3 +144,55 @@ def test_eval_zoo_loads_and_averages_checkpoints(tmp_path):
     assert tp.shape == (2, c["embed_dim"]) and words.shape == (2, c["ctx"], c["t_width"]) and pm.shape == (2, c["ctx"])
     single = MyModelZoo(cfg, paths[0])
     assert torch.equal(single.model.space_dict.detach().cpu(), torch.from_numpy(det_state(state_shapes(c, True), 11)["space_dict"]))
+
+
+def test_solver_with_string_captions_through_the_prefetcher(tmp_path, golden_dir):
+    """A loader that yields what the reference's does -- (CPU image batch, list of caption strings): the prefetcher thread
+    tokenises with the C++ BPE, stages the batch on the device one step ahead and hands the caption lengths to the model
+    (packed text rows).  The same batches fed as pre-tokenised device tensors must give the same losses."""
+    import yaml
+    from ilvlm_amd import solver as S
+    c = CFG["a"]
+    kw = model_kwargs(c, FDT_VARIANTS[0], bpe_path=os.path.join(golden_dir, "bpe_simple_vocab_16e6.txt.gz"))
+    kw["precision"] = "fp32"
+    cfg = dict(
+        model=dict(type="clip_fdt_vitb32", kwargs=kw),
+        grad_clip=dict(type="logit_scale_param_value", value=3, max_value=6),
+        t_decay=dict(org_t=1000, sd_T_decay_iter=100, sd_T_decay_w=1.0, sd_T_min=0.01),
+        optimizer=dict(type="AdamW", kwargs=dict(lr=5e-5, weight_decay=0.1, betas=[0.9, 0.98], amsgrad=False, eps=1e-8),
+                       pconfig={k: dict(weight_decay=0) for k in ("bn_w", "bn_b", "ln_w", "ln_b", "bias", "logit_scale")}),
+        lr_scheduler=dict(type="Cosine", kwargs=dict(base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0, warmup_steps=2, max_iter=40)),
+        data=dict(train=dict(epoch=1, batch_size=4, num_samples=16, num_shards=1, workers=0, transforms="none",
+                             data_path="none"), test=dict()),
+        saver=dict(print_freq=1, val_freq=100, save_freq=100, save_many=True),
+        reset=dict(enable=False, reset_steps=0, reset_nums=0, save_freq=1, smooth_steps=0, distil_steps=0))
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    caps = [["a photo of a cat", "two dogs, one brown & one white!", "the quick brown fox jumps over the lazy dog", "hello"],
+            ["it's a dog's life; isn't it?", "1234 numbers 56 and 7.89", "CAPS LOCK TEXT", "café au lait"],
+            ["", "  extra   spaces   here  ", "a man riding a wave on top of a surfboard.", "x"]]
+    g = torch.Generator().manual_seed(3)
+    images = [torch.randn(4, 3, c["res"], c["res"], generator=g) for _ in caps]
+
+    class Loader(list):
+        num_batches = 3
+
+    def run(batches, name):
+        args = S.argparse.Namespace(config=str(path), output_path=str(tmp_path / name), batch_size=4, debug=True, exp_name=name,
+                                    ckpt_path="", synthetic=False, max_steps=3, lipreg=0)
+        sol = S.ClsSolver(args, train_data=Loader(batches))
+        return sol, sol.train()
+
+    sol, losses = run(list(zip(images, caps)), "strings")
+    assert isinstance(sol.train_data, S.DevicePrefetcher)
+    tt = sol.model.module.encode_text
+    pre = []
+    for img, cp in zip(images, caps):
+        tok, mask = tt.tokenize(cp)
+        pre.append((img.cuda(), (tok.cuda(), mask.cuda())))          # device tensors without lengths: all positions
+    os.environ["ILVLM_PREFETCH"] = "0"
+    try:
+        _, losses2 = run(pre, "tensors")
+    finally:
+        del os.environ["ILVLM_PREFETCH"]
+    assert len(losses) == 3 and np.allclose(losses, losses2, rtol=2e-5, atol=1e-6), (losses, losses2)
