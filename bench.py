@@ -235,8 +235,10 @@ def main():
             pass
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16, unit="TFLOP/s",
                         frac=round(achieved / PEAK_BF16, 4), traffic=traffic,
-                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 (gfx950), bytes per launch; "
-                                       "algorithmic bytes per launch ~ 45e6 (profiles/round1/hbm_traffic.json)",
+                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 (gfx950), L2-miss bytes per "
+                                       "launch (profiles/round1/hbm_traffic.json); algorithmic_bytes_per_launch = operands + "
+                                       "output + epilogue operands once each, from the launches timed here",
+                        algorithmic_bytes_per_launch=round(s["bytes"] / max(s["launches"], 1)),
                         kernel="gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step, towers serialised for timing)",
                         launches_per_step=s["launches"] // nprof,
                         gemm_ms_per_step=round(s["ms"] / nprof, 3),

@@ -51,12 +51,13 @@ class GemmProfiler:
     """Brackets every bf16 GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
 
     def __init__(self):
-        self.records = []     # (start_event, end_event, flops)
+        self.records = []     # (start_event, end_event, flops, algorithmic bytes)
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        return dict(launches=len(self.records), ms=ms, flops=float(sum(f for _, _, f in self.records)))
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=float(sum(r[2] for r in self.records)),
+                    bytes=float(sum(r[3] for r in self.records)))
 
 
 _gemm_profiler = None
@@ -111,7 +112,11 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
                                 out.data_ptr(), ldc, C.byref(epi), int(split_k), _stream()), "gemm")
     if prof is not None:
         ev1.record()
-        prof.records.append((ev0, ev1, 2.0 * m * n * k))
+        # algorithmic HBM bytes: both operands once, the output once (read-modify-write when accumulating), every
+        # epilogue operand once
+        nbytes = 2.0 * (m * k + n * k) + m * n * out.element_size() * (2 if accumulate else 1)
+        nbytes += m * n * (4 if residual is not None else 0) + (m * n * aux.element_size() if aux is not None else 0)
+        prof.records.append((ev0, ev1, 2.0 * m * n * k, nbytes))
     return out
 
 

@@ -148,8 +148,13 @@ class DevicePrefetcher:
                 raise item
             image, text, done = item
             if done is not None:
-                torch.cuda.current_stream(self.device).wait_event(done)     # order the step after the copies
-                image.record_stream(torch.cuda.current_stream(self.device))
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(done)                                        # order the step after the copies
+                image.record_stream(cur)
+                if isinstance(text, tuple):
+                    for t in text:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
             yield image, text
         t.join()
 
