@@ -328,8 +328,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <bool TR, int ROWS, int NTHREADS, int BKT>
 struct DmaOperand {
     static constexpr int NLOAD = ROWS * BKT * 2 / (NTHREADS * 16);   // loads per thread per K-tile
+    // K-contiguous operands: load j of a wave is 64 / (BKT / 8) rows below load j - 1 and the chunk swizzle depends on
+    // the row only modulo 8, so one per-lane offset plus a scalar step serves all loads (register budget of the
+    // 256x128 tile); K-strided operands keep one offset per load
+    static constexpr int NVOFF = TR ? NLOAD : 1;
     __amdgpu_buffer_rsrc_t rs;
-    int voff[NLOAD];
+    int voff[NVOFF];
+    int jstep;
     int tile_off;    // byte offset of this workgroup's tile at k = 0
     int k_step;      // byte offset added per K-tile
 
@@ -337,8 +342,9 @@ struct DmaOperand {
         const long elems = !TR ? (long)(R - 1) * ld + K : (long)(K - 1) * ld + R;
         const long bytes = elems * 2;
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+        jstep = !TR ? (BKT == 64 ? 8 : 16) * ld * 2 : 0;
 #pragma unroll
-        for (int j = 0; j < NLOAD; ++j) {
+        for (int j = 0; j < NVOFF; ++j) {
             const int s = (wave * NLOAD + j) * 64 + lane;
             if (!TR) {
                 // BKT = 64: 128-byte rows, chunk ^ (row & 7); BKT = 32: 64-byte rows, chunk ^ ((row >> 2) & 3)
@@ -360,7 +366,7 @@ struct DmaOperand {
 #pragma unroll
         for (int j = 0; j < NLOAD; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
-                                                     16, voff[j], soff, 0, 0);
+                                                     16, voff[TR ? j : 0], soff + (TR ? 0 : j * jstep), 0, 0);
     }
 };
 #endif
