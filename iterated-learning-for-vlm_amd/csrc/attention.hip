@@ -6,8 +6,9 @@
 //   (wave = key tile) gives dK and dV with register accumulators, so no cross-wave reduction and one barrier in the
 //   whole kernel; P and dS are recomputed from the saved log-sum-exp in both passes (the MFMAs are not the bottleneck).
 //   41 KB of LDS at L = 77 (was 95 KB): 3 workgroups x 5 waves per CU instead of 1 x 4.
-//   128 < L <= 288 (ViT-B/16 197, ViT-L/14 257 tokens): K/V resident, probabilities per 64-row query round (forward)
-//   or per 32-key block (backward).
+//   128 < L <= 288 (ViT-B/16 197, ViT-L/14 257 tokens): the forward is the same kernel with 8 waves walking the
+//   10..18 tiles; the backward keeps Q / dO resident and sweeps the keys in blocks of 32 with dQ in registers (a
+//   wave-per-tile backward would hold up to 18 tiles of dS per wave and spills).
 // bf16 path: all products on v_mfma_f32_16x16x32_bf16, K-strided operands fetched with ds_read_b64_tr_b16 (no
 // transposed copies), fp32 softmax, only the row log-sum-exp is saved for backward.  fp32 path: plain VALU kernel used
 // by the fp32 parity mode.
@@ -89,11 +90,11 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16* src, long row_stride, 
 // ---------------------------------------------------------------------------------------------
 // L <= 128: one wave per 16-row tile (NT = ceil(L / 16) waves per workgroup)
 // ---------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_wave(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                          float* __restrict__ lse, int Lmax, int H, int causal,
                                                          const int* __restrict__ seq_offs) {
-    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
+    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Ks = (bf16*)smem_raw;          // [ROWS][72]
     bf16* Vs = Ks + ROWS * LDH;          // [ROWS][72]
@@ -106,21 +107,28 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
     const int L = seq_offs ? seq_offs[b + 1] - seq_offs[b] : Lmax;
     const bf16* base = qkv + row0 * rs + h * HD;
     const int g = lane >> 4, c16 = lane & 15;
-    const int q = wave * 16 + c16;
-    // the wave's Q tile as B operand (column = query), pre-scaled by 1/sqrt(64) (exact in bf16)
+    // the Q tile as B operand (column = query), pre-scaled by 1/sqrt(64) (exact in bf16); the first tile's fragments are
+    // requested before the staging loop
     bf16x8 qb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        qb[ks] = frag_global(base, rs, q, L, ks * 32, lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qb[ks][j] = (bf16)((float)qb[ks][j] * 0.125f);
-    }
+    for (int ks = 0; ks < 2; ++ks) qb[ks] = frag_global(base, rs, wave * 16 + c16, L, ks * 32, lane);
     stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
     stage_rows<ROWS, NTH>(Vs, base + 2 * E, rs, L, 1.0f, tid);
     __syncthreads();
-    if (wave * 16 >= L) return;                        // a shorter packed sequence: this tile has no rows (after the only barrier)
+    // NW == NT: one tile per wave; longer sequences (NW = 8 < NT): the wave walks tiles wave, wave + 8, ...
+    for (int tile = wave; tile < NT; tile += NW) {
+    if (tile * 16 >= L) break;                         // a shorter (packed) sequence: no rows here (after the only barrier)
+    const int q = tile * 16 + c16;
+    if (tile != wave) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qb[ks] = frag_global(base, rs, q, L, ks * 32, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qb[ks][j] = (bf16)((float)qb[ks][j] * 0.125f);
 
-    const int nkt = causal ? min(NT, wave + 1) : NT;   // key tiles this query tile can see (wave-uniform)
+    const int nkt = causal ? min(NT, tile + 1) : NT;   // key tiles this query tile can see (wave-uniform)
     f32x4 s[NT];                                       // s[kt][r] = S[q][key = 16 kt + 4 g + r]
     float m = -INFINITY;
 #pragma unroll
@@ -174,14 +182,15 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_wave(const bf16* __restrict_
             *(bf16x4*)(out + (row0 + q) * E + h * HD + dt * 16 + 4 * g) = ov;
         }
     }
+    }
 }
 
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
                                                          const bf16* __restrict__ outp, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, int Lmax, int H, int causal,
                                                          const int* __restrict__ seq_offs) {
-    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NT;
+    constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Qs = (bf16*)smem_raw;          // [ROWS][72], pre-scaled by 1/8
     bf16* Ks = Qs + ROWS * LDH;
@@ -236,15 +245,15 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
     }
     for (int r = tid; r < ROWS; r += NTH) lses[r] = r < L ? lse[((long)b * H + h) * Lmax + r] : 0.f;
     __syncthreads();
-    if (wave * 16 >= L) return;                        // shorter packed sequence: no rows in this tile
-
     const int g = lane >> 4, c16 = lane & 15;
-    {   // ---- pass A: dQ of query tile `wave`.  Transposed products: lane (g, c16 = q) holds keys 16 kt + 4 g + r.
-        const int q = wave * 16 + c16;
-        const bf16x8 qb0 = frag_k(Qs, LDH, wave * 16, 0, lane), qb1 = frag_k(Qs, LDH, wave * 16, 32, lane);
-        const bf16x8 db0 = frag_k(dOs, LDH, wave * 16, 0, lane), db1 = frag_k(dOs, LDH, wave * 16, 32, lane);
+    for (int tile = wave; tile < NT; tile += NW) {
+        if (tile * 16 >= L) break;                     // shorter (packed) sequence: no rows in this tile
+        // ---- pass A: dQ of query tile `tile`.  Transposed products: lane (g, c16 = q) holds keys 16 kt + 4 g + r.
+        const int q = tile * 16 + c16;
+        const bf16x8 qb0 = frag_k(Qs, LDH, tile * 16, 0, lane), qb1 = frag_k(Qs, LDH, tile * 16, 32, lane);
+        const bf16x8 db0 = frag_k(dOs, LDH, tile * 16, 0, lane), db1 = frag_k(dOs, LDH, tile * 16, 32, lane);
         const float lq = lses[q], dl = delta[q];
-        const int nkt = causal ? min(NT, wave + 1) : NT;
+        const int nkt = causal ? min(NT, tile + 1) : NT;
         bf16x4 ds[NTE];
 #pragma unroll
         for (int kt = 0; kt < NTE; ++kt) {
@@ -279,22 +288,24 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_wave(const bf16* __restrict_
             }
         }
     }
-    {   // ---- pass B: dK, dV of key tile `wave`.  Plain products: lane (g, c16 = key) holds queries 16 qt + 4 g + r.
-        const int key = wave * 16 + c16;
-        const bf16x8 kb0 = frag_k(Ks, LDH, wave * 16, 0, lane), kb1 = frag_k(Ks, LDH, wave * 16, 32, lane);
+    for (int tile = wave; tile < NT; tile += NW) {
+        if (tile * 16 >= L) break;
+        // ---- pass B: dK, dV of key tile `tile`.  Plain products: lane (g, c16 = key) holds queries 16 qt + 4 g + r.
+        const int key = tile * 16 + c16;
+        const bf16x8 kb0 = frag_k(Ks, LDH, tile * 16, 0, lane), kb1 = frag_k(Ks, LDH, tile * 16, 32, lane);
         bf16x8 vb0, vb1;                                // this wave's own key tile
         if (PREV) {                                     // wave-uniform select, no register indexing
             vb0 = vf[0][0]; vb1 = vf[0][1];
 #pragma unroll
             for (int kt = 1; kt < NT; ++kt)
-                if (kt == wave) { vb0 = vf[PREV ? kt : 0][0]; vb1 = vf[PREV ? kt : 0][1]; }
+                if (kt == tile) { vb0 = vf[PREV ? kt : 0][0]; vb1 = vf[PREV ? kt : 0][1]; }
         } else {
             vb0 = frag_global(vbase, rs, key, L, 0, lane); vb1 = frag_global(vbase, rs, key, L, 32, lane);
         }
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0, 0, 0, 0}; dv[dt] = (f32x4){0, 0, 0, 0}; }
-        const int qt0 = causal ? wave : 0;           // query tiles below the key tile are fully masked
+        const int qt0 = causal ? tile : 0;           // query tiles below the key tile are fully masked
 #pragma unroll
         for (int kp = 0; kp < NTE / 2; ++kp) {
             if (2 * kp + 1 >= qt0) {
@@ -356,96 +367,6 @@ __device__ __forceinline__ void load_rows(bf16* dst, const bf16* src, long row_s
         *(bf16x8*)(dst + r * LDH + ch * 8) = v;
     }
 }
-
-template <int LP>
-__global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                     float* __restrict__ lse, int L, int H, int causal) {
-    constexpr int NT = LP / 16, LDP = LP + 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16* Qs = (bf16*)smem_raw;
-    bf16* Ks = Qs + LP * LDH;
-    bf16* Vt = Ks + LP * LDH;          // [64][LDP]  (V transposed)
-    bf16* Ps = Vt + HD * LDP;          // [64][LDP]: the 4 waves' 16-row slices of the current round
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int E = HD * H;
-    const long rs = 3L * E;
-    const bf16* base = qkv + (long)b * L * rs + h * HD;
-    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
-    load_rows<LP>(Ks, base + E, rs, L, 1.0f, tid);
-    for (int c = tid; c < LP * 8; c += 256) {
-        int r = c >> 3, ch = c & 7;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < L) v = *(const bf16x8*)(base + 2 * E + r * rs + ch * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * LDP + r] = v[j];
-    }
-    __syncthreads();
-
-    const int nqt = (L + 15) / 16;
-    const int g = lane >> 4, c16 = lane & 15;
-    for (int it = 0; it * 4 < nqt; ++it) {
-        const int qt = it * 4 + wave;
-        const bool active = qt < nqt;   // wave-uniform
-        if (active) {
-            f32x4 s[NT];
-            bf16x8 qa0 = frag_k(Qs, LDH, qt * 16, 0, lane), qa1 = frag_k(Qs, LDH, qt * 16, 32, lane);
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x4 a = {0, 0, 0, 0};
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(Ks, LDH, kt * 16, 0, lane), a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(Ks, LDH, kt * 16, 32, lane), a, 0, 0, 0);
-                s[kt] = a;   // s[kt][r] = S[q = qt*16 + 4g + r][key = kt*16 + c16]
-            }
-            float mx[4], sm[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qt * 16 + 4 * g + r;
-                float m = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) {
-                    const int key = kt * 16 + c16;
-                    const bool ok = key < L && (!causal || key <= q);
-                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
-                    m = fmaxf(m, s[kt][r]);
-                }
-                m = group16_max(m);
-                float t = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) {
-                    float e = __expf(s[kt][r] - m);
-                    s[kt][r] = e;
-                    t += e;
-                }
-                t = group16_sum(t);
-                mx[r] = m; sm[r] = t;
-                const float inv = 1.0f / t;
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) Ps[(wave * 16 + 4 * g + r) * LDP + kt * 16 + c16] = (bf16)(s[kt][r] * inv);
-                if (c16 == 0 && q < L) lse[((long)b * H + h) * L + q] = m + __logf(t);
-            }
-            (void)mx; (void)sm;
-        }
-        __syncthreads();   // P rows of this round visible (each wave only re-reads its own 16 rows)
-        if (active) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < LP / 32; ++ks)   // D[d][q] = sum_key Vt[d][key] * P[q][key]
-                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Vt, LDP, dt * 16, ks * 32, lane),
-                                                                frag_k(Ps, LDP, wave * 16, ks * 32, lane), o, 0, 0, 0);
-                const int q = qt * 16 + c16;
-                if (q < L) {
-                    bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-                    *(bf16x4*)(out + ((long)b * L + q) * E + h * HD + dt * 16 + 4 * g) = ov;
-                }
-            }
-        }
-        __syncthreads();   // this round's P slices are consumed before the next round overwrites them
-    }
-}
-
 
 // Backward for 128 < L <= 288 (ViT-L/14: 257 tokens): the L x L probabilities no longer fit in LDS, so keys are swept in
 // blocks of 32.  Q, dO (whole sequence) stay resident; per key block: P and dS for all query rows (each wave its own
@@ -705,35 +626,37 @@ int set_lds(K kern, int bytes, const char* name) {
     return ILVLM_OK;
 }
 
-template <int LP>
-int launch_fwd_bf16(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, hipStream_t s) {
-    constexpr int LDP = LP + 8;
-    constexpr int bytes = (2 * LP * LDH + HD * LDP + 64 * LDP) * 2;
-    static bool done = false;   // per instantiation; the attribute is idempotent
-    if (!done) {
-        int rc = set_lds(attn_fwd_bf16<LP>, bytes, "attention_fwd");
-        if (rc) return rc;
-        done = true;
-    }
-    hipLaunchKernelGGL((attn_fwd_bf16<LP>), dim3(B * H), dim3(256), bytes, s, qkv, out, lse, L, H, causal);
-    ILVLM_LAUNCH_CHECK("attention_fwd");
-    return ILVLM_OK;
-}
-template <int NT>
+template <int NT, int NW = NT>
 int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, const int* seq_offs,
                     hipStream_t s) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 2 * ROWS * LDH * 2;
-    hipLaunchKernelGGL((attn_fwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, qkv, out, lse, L, H, causal, seq_offs);
+    if (bytes > 64 * 1024) {
+        static bool done = false;   // per instantiation; the attribute is idempotent
+        if (!done) {
+            int rc = set_lds(attn_fwd_wave<NT, NW>, bytes, "attention_fwd");
+            if (rc) return rc;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, qkv, out, lse, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_fwd");
     return ILVLM_OK;
 }
-template <int NT>
+template <int NT, int NW = NT>
 int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
                     int causal, const int* seq_offs, hipStream_t s) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
-    constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // <= 57 KB: below the 64 KB default limit
-    hipLaunchKernelGGL((attn_bwd_wave<NT>), dim3(B * H), dim3(64 * NT), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal,
+    constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // 57 KB at 128 tokens, 127 KB at 288
+    if (bytes > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            int rc = set_lds(attn_bwd_wave<NT, NW>, bytes, "attention_bwd");
+            if (rc) return rc;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_bwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal,
                        seq_offs);
     ILVLM_LAUNCH_CHECK("attention_bwd");
     return ILVLM_OK;
@@ -777,11 +700,14 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype,
             case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, seq_offs, s);
             case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, seq_offs, s);
             case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 9: case 10: return launch_fwd_wave<10, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 11: case 12: return launch_fwd_wave<12, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 13: case 14: return launch_fwd_wave<14, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 15: case 16: return launch_fwd_wave<16, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 17: case 18: return launch_fwd_wave<18, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
             default: break;
         }
-        if (L <= 192) return launch_fwd_bf16<192>(q, o, lse, B, L, H, causal, s);
-        if (L <= 224) return launch_fwd_bf16<224>(q, o, lse, B, L, H, causal, s);
-        return launch_fwd_bf16<288>(q, o, lse, B, L, H, causal, s);
+        ILVLM_FAIL(ILVLM_ERR_ARG, "attention_fwd(bf16): no kernel for L=%d", L);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_fwd: bad dtype %d", dtype);
     ILVLM_REQUIRE(L <= 96, "attention_fwd(f32): L=%d > 96 not supported", L);
@@ -825,6 +751,8 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
             case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
             case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
             case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            // longer sequences: the wave-per-tile backward would hold 14-18 tiles of dS per wave and spills at 256 VGPRs
+            // (425 us against 325 us for the key-block kernel below at L = 257); the forward does profit (190 -> 117 us)
             default: break;
         }
         if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s);
