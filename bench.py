@@ -262,6 +262,13 @@ def main():
             acc.setdefault("%s -> %s" % (n0, n1), []).append(e0.elapsed_time(e1))
         for k, v in acc.items():
             print("phase %-40s %7.3f ms" % (k, sum(v) / len(v)), file=sys.stderr, flush=True)
+        hs = []
+        for _ in range(5):              # host cost of enqueueing one step into an idle GPU (no queue back-pressure)
+            torch.cuda.synchronize()
+            t0h = time.perf_counter()
+            one_step()
+            hs.append(1000.0 * (time.perf_counter() - t0h))
+        print("phase %-40s %7.3f ms" % ("host enqueue of one step, GPU idle", sorted(hs)[2]), file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "vitb32":
         cpu = cpu_baseline()

@@ -120,6 +120,7 @@ class Engine:
         # only needed by the gradient reduction / optimizer): -1.3 % step time; stream priorities added nothing
         self.wgrad_streams = os.environ.get("ILVLM_WGRAD_STREAMS", "1") == "1"
         self._wg = {}
+        self._wg_keep = {}      # tower stream -> tensors its companion stream still reads
 
     @property
     def side_stream(self):
@@ -161,6 +162,8 @@ class Engine:
         wg = self._wg.get(torch.cuda.current_stream().cuda_stream)
         if wg is not None:
             torch.cuda.current_stream().wait_stream(wg)
+            # tensors freed from here on are reused by work enqueued after this join, i.e. after the weight gradients
+            self._wg_keep.pop(torch.cuda.current_stream().cuda_stream, None)
 
     def _mat(self, name):
         w = self.Wc[name]
@@ -175,13 +178,13 @@ class Engine:
         fuse_b = need_b and self.req[wname] and self.T == torch.bfloat16 and ops.rowsum_fusable(N, M)
         wg = self._wgrad_stream()
         if wg is not None:                   # weight gradients are off the dgrad chain: a companion stream takes them
-            cur = torch.cuda.current_stream()
-            wg.wait_stream(cur)
-            dy.record_stream(wg); x.record_stream(wg)
-            ctx = torch.cuda.stream(wg)
-        else:
-            ctx = contextlib.nullcontext()
-        with ctx:
+            wg.wait_stream(torch.cuda.current_stream())
+            # the operands must outlive the launch: the saved activation x does (the autograd node holds it until backward
+            # returns, after join_wgrad); dy is kept referenced until the join instead of paying record_stream's
+            # allocator events
+            self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(dy)
+            ops._stream_override = wg.cuda_stream          # cheaper than entering a torch stream context per GEMM
+        try:
             if self.req[wname]:
                 # dW[N,K] += dy^T x ; the bias gradient sum_m dy[m,:] rides along as the row sums of the A operand
                 ops.gemm(dy, x, self.Gr[wname].reshape(N, -1), trans_a=True, trans_b=True, accumulate=True,
@@ -189,6 +192,8 @@ class Engine:
                          a_rowsum=self.Gr[bname] if fuse_b else None)
             if need_b and not fuse_b:
                 ops.colsum(dy, self.Gr[bname])
+        finally:
+            ops._stream_override = None
         if not need_dx:
             return None
         dx = _empty((M, K), self.T, dy)

@@ -21,7 +21,12 @@ def torch_dtype(code):
     return torch.float32 if code == F32 else torch.bfloat16
 
 
+_stream_override = None     # raw stream handle: launches go there instead of the current stream (engine, wgrad stream)
+
+
 def _stream():
+    if _stream_override is not None:
+        return _stream_override
     return torch.cuda.current_stream().cuda_stream
 
 
