@@ -193,6 +193,35 @@ int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* e
                      const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
                      int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream);
 
+/* ---- composite: one residual attention block per call (image_encoder/base_transformer.py:29-62, text twin
+ * text_encoder/base_transformer.py:29-59): x_mid = x + out_proj(attn(in_proj(ln_1 x))), x_out = x_mid +
+ * c_proj(QuickGELU(c_fc(ln_2 x_mid))).  The calls only sequence the kernels above, in the order the host engine issues
+ * them one by one; they exist to cut host time (48 calls instead of ~800 per step).  The caller owns all memory:
+ * `saved` (ilvlm_block_saved_bytes) receives the activations the backward needs, `scratch` (ilvlm_block_scratch_bytes)
+ * holds the backward temporaries and must stay untouched until the weight-gradient stream has been joined.
+ * dtype: ILVLM_BF16 (GEMM weights = bf16 shadow, activations bf16, fp32 residual stream) or ILVLM_F32.
+ * Gradient pointers accumulate (+=); NULL marks a frozen weight / bias (LayerNorm parameters must be trainable).
+ * seq_offs != NULL: packed text rows (below), rows = total valid tokens; else rows = B * L.
+ * wgrad_stream (nullable): weight-gradient GEMMs are issued there, ordered after their operands by events. */
+typedef struct ilvlm_block {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const void *in_w, *out_w, *fc_w, *proj_w;      /* [3E,E] [E,E] [4E,E] [E,4E], compute dtype */
+    const float *in_b, *out_b, *fc_b, *proj_b;
+    float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b, *g_in_w, *g_in_b, *g_out_w, *g_out_b, *g_fc_w, *g_fc_b, *g_proj_w,
+        *g_proj_b;
+    int E, H, causal, dtype;
+} ilvlm_block;
+long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L);
+long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);
+int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x_out, void* saved, long rows, int B, int L, int Lcap,
+                    const int32_t* seq_offs, void* stream);
+/* dx_f32 / dx_lp: gradient of the block output (fp32, and its compute-dtype copy in bf16 mode); din_*: the same for the
+ * block input.  ln_ws: 2 * ln_ws_blocks * E floats (LayerNorm second stage).  wgrad_target: workgroups a split-K
+ * weight-gradient launch should reach (384 fills the chip). */
+int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32, const void* dx_lp,
+                    float* din_f32, void* din_lp, void* scratch, float* ln_ws, int ln_ws_blocks, long rows, int B, int L,
+                    int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream);
+
 /* ---- packed text rows.  Positions behind <|endoftext|> never reach the loss: attention is causal
  * (text_transformer.py:147-153), the FDT scores of masked tokens are multiplied by zero (clip_fdt.py:118-123) and the
  * pooled feature is read at the EOT position (text_transformer.py:248).  The training step therefore may run the text

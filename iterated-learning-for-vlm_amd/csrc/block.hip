@@ -1,0 +1,205 @@
+// Composite entry points: one residual attention block (reference image_encoder/base_transformer.py:29-62, text twin
+// text_encoder/base_transformer.py:29-59) forward or backward per C call.  They only sequence the kernels of this
+// library (LayerNorm, GEMM, attention) exactly as the Python engine does one by one; the point is host time: a step
+// issues ~600 launches, and at ~15-20 us of interpreter + ctypes work each the host needs 12-16 ms per step against 19 ms
+// of GPU work.  24 blocks x (13 forward + 21 backward) launches become 48 calls.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+inline int esz(int dtype) { return dtype == ILVLM_BF16 ? 2 : 4; }
+
+struct Saved {   // byte offsets into the saved-activation workspace of one block
+    size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, total;
+    Saved(const ilvlm_block* b, long rows, int B, int L) {
+        const size_t E = b->E, es = esz(b->dtype), r = rows;
+        size_t o = 0;
+        x_mid = o; o += al(r * E * 4);
+        h1 = o; o += al(r * E * es);
+        qkv = o; o += al(r * 3 * E * es);
+        att = o; o += al(r * E * es);
+        h2 = o; o += al(r * E * es);
+        u = o; o += al(r * 4 * E * es);
+        g = o; o += al(r * 4 * E * es);
+        mean1 = o; o += al(r * 4);
+        rstd1 = o; o += al(r * 4);
+        mean2 = o; o += al(r * 4);
+        rstd2 = o; o += al(r * 4);
+        lse = o; o += al((size_t)B * b->H * L * 4);
+        total = o;
+    }
+};
+
+struct Scratch {   // backward temporaries
+    size_t du, dh2, dmid, dmid_lp, da, dqkv, dh1, total;
+    Scratch(const ilvlm_block* b, long rows) {
+        const size_t E = b->E, es = esz(b->dtype), r = rows;
+        size_t o = 0;
+        du = o; o += al(r * 4 * E * es);
+        dh2 = o; o += al(r * E * es);
+        dmid = o; o += al(r * E * 4);
+        dmid_lp = o; o += al(r * E * es);
+        da = o; o += al(r * E * es);
+        dqkv = o; o += al(r * 3 * E * es);
+        dh1 = o; o += al(r * E * es);
+        total = o;
+    }
+};
+
+int check_block(const ilvlm_block* b, const char* who) {
+    ILVLM_REQUIRE(b, "%s: null block descriptor", who);
+    ILVLM_REQUIRE(b->dtype == ILVLM_BF16 || b->dtype == ILVLM_F32, "%s: bad dtype %d", who, b->dtype);
+    ILVLM_REQUIRE(b->E > 0 && b->H > 0 && b->E == 64 * b->H, "%s: width %d must be 64 x heads (%d)", who, b->E, b->H);
+    ILVLM_REQUIRE(b->ln1_w && b->ln1_b && b->ln2_w && b->ln2_b && b->in_w && b->in_b && b->out_w && b->out_b && b->fc_w &&
+                      b->fc_b && b->proj_w && b->proj_b, "%s: null parameter pointer", who);
+    return ILVLM_OK;
+}
+
+// split-K of a weight-gradient GEMM: enough workgroups to fill the chip (ops.wgrad_split)
+int wgrad_split(long out_rows, long out_cols, long k, int tile, int target) {
+    const long tiles = ((out_rows + tile - 1) / tile) * ((out_cols + tile - 1) / tile);
+    long s = (long)nearbyint((double)target / (double)tiles);      // round-half-even, as Python's round()
+    s = s < 1 ? 1 : (s > 16 ? 16 : s);
+    const long cap = k >= 256 ? k / 256 : 1;
+    s = s < cap ? s : cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
+#define TRY(call)            \
+    do {                     \
+        int rc__ = (call);   \
+        if (rc__) return rc__; \
+    } while (0)
+
+// dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s
+int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
+               int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg) {
+    const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
+    if (gW || gb) {
+        hipStream_t ws = s;
+        if (wg && wg != s) {     // weight gradients leave the dgrad chain (engine._linear_bwd)
+            hipEvent_t ev;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: hipEventCreate: %s", hipGetErrorString(e));
+            e = hipEventRecord(ev, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(wg, ev, 0);
+            hipError_t e2 = hipEventDestroy(ev);       // destruction is deferred until the event has completed
+            if (e == hipSuccess) e = e2;
+            if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: stream ordering: %s", hipGetErrorString(e));
+            ws = wg;
+        }
+        if (gW) {
+            ilvlm_gemm_epilogue ep = {};
+            ep.alpha = 1.0f;
+            ep.out_dtype = ILVLM_F32;
+            ep.accumulate = 1;
+            ep.a_rowsum = fuse_b ? gb : nullptr;
+            TRY(ilvlm_gemm(dtype, 1, 1, N, K, (int)M, dy, N, x, K, gW, K, &ep,
+                           wgrad_split(N, K, M, dtype == ILVLM_BF16 ? 128 : 64, wgrad_target), ws));
+        }
+        if (gb && !fuse_b) TRY(ilvlm_colsum(dy, dtype, gb, M, N, N, ws));
+    }
+    ilvlm_gemm_epilogue ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = dtype;
+    ep.act = dx_act;
+    ep.aux = (void*)dx_aux;
+    return ilvlm_gemm(dtype, 0, 1, (int)M, K, N, dy, N, W, K, dx, K, &ep, 1, s);
+}
+
+}  // namespace
+
+extern "C" long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L) {
+    if (!b || rows <= 0 || B <= 0 || L <= 0) return -1;
+    return (long)Saved(b, rows, B, L).total;
+}
+extern "C" long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows) {
+    if (!b || rows <= 0) return -1;
+    return (long)Scratch(b, rows).total;
+}
+
+extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x_out, void* saved, long rows, int B, int L,
+                               int Lcap, const int32_t* seq_offs, void* stream) {
+    TRY(check_block(b, "block_fwd"));
+    ILVLM_REQUIRE(x_in && x_out && saved && rows > 0 && B > 0 && L > 0, "block_fwd: bad arguments");
+    ILVLM_REQUIRE(seq_offs || rows == (long)B * L, "block_fwd: rows=%ld is not B*L=%ld (dense layout)", rows, (long)B * L);
+    const Saved o(b, rows, B, L);
+    char* w = (char*)saved;
+    const int E = b->E, T = b->dtype;
+    float *mean1 = (float*)(w + o.mean1), *rstd1 = (float*)(w + o.rstd1), *mean2 = (float*)(w + o.mean2),
+          *rstd2 = (float*)(w + o.rstd2), *lse = (float*)(w + o.lse), *x_mid = (float*)(w + o.x_mid);
+    void *h1 = w + o.h1, *qkv = w + o.qkv, *att = w + o.att, *h2 = w + o.h2, *u = w + o.u, *g = w + o.g;
+    // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
+    TRY(ilvlm_layernorm_fwd(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, stream));
+    ilvlm_gemm_epilogue ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = T;
+    ep.bias = b->in_b;
+    TRY(ilvlm_gemm(T, 0, 0, (int)rows, 3 * E, E, h1, E, b->in_w, E, qkv, 3 * E, &ep, 1, stream));
+    if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
+    else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
+    ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = ILVLM_F32;
+    ep.bias = b->out_b;
+    ep.residual = x_in;
+    TRY(ilvlm_gemm(T, 0, 0, (int)rows, E, E, att, E, b->out_w, E, x_mid, E, &ep, 1, stream));
+    // x_out = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
+    TRY(ilvlm_layernorm_fwd(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, stream));
+    ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = T;
+    ep.bias = b->fc_b;
+    ep.aux = u;
+    ep.act = ILVLM_ACT_QUICKGELU;
+    TRY(ilvlm_gemm(T, 0, 0, (int)rows, 4 * E, E, h2, E, b->fc_w, E, g, 4 * E, &ep, 1, stream));
+    ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = ILVLM_F32;
+    ep.bias = b->proj_b;
+    ep.residual = x_mid;
+    return ilvlm_gemm(T, 0, 0, (int)rows, E, 4 * E, g, 4 * E, b->proj_w, 4 * E, x_out, E, &ep, 1, stream);
+}
+
+extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32,
+                               const void* dx_lp, float* din_f32, void* din_lp, void* scratch, float* ln_ws,
+                               int ln_ws_blocks, long rows, int B, int L, int Lcap, const int32_t* seq_offs,
+                               int wgrad_target, void* stream, void* wgrad_stream) {
+    TRY(check_block(b, "block_bwd"));
+    ILVLM_REQUIRE(x_in && saved && dx_f32 && din_f32 && scratch && rows > 0 && B > 0 && L > 0, "block_bwd: bad arguments");
+    const int E = b->E, T = b->dtype;
+    const bool lp = T != ILVLM_F32;
+    ILVLM_REQUIRE(!lp || (dx_lp && din_lp), "block_bwd: the low-precision gradient copies are required in bf16 mode");
+    ILVLM_REQUIRE(wgrad_target > 0, "block_bwd: wgrad_target must be positive");
+    const Saved o(b, rows, B, L);
+    const Scratch c(b, rows);
+    const char* w = (const char*)saved;
+    char* t = (char*)scratch;
+    hipStream_t s = (hipStream_t)stream, wg = (hipStream_t)wgrad_stream;
+    const float *mean1 = (const float*)(w + o.mean1), *rstd1 = (const float*)(w + o.rstd1),
+                *mean2 = (const float*)(w + o.mean2), *rstd2 = (const float*)(w + o.rstd2),
+                *lse = (const float*)(w + o.lse), *x_mid = (const float*)(w + o.x_mid);
+    const void *h1 = w + o.h1, *qkv = w + o.qkv, *att = w + o.att, *h2 = w + o.h2, *u = w + o.u, *g = w + o.g;
+    void *du = t + c.du, *dh2 = t + c.dh2, *da = t + c.da, *dqkv = t + c.dqkv, *dh1 = t + c.dh1;
+    float* dmid = (float*)(t + c.dmid);
+    void* dmid_lp = lp ? (void*)(t + c.dmid_lp) : nullptr;
+    // MLP
+    const void* dy = lp ? dx_lp : (const void*)dx_f32;
+    TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg));
+    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg));
+    ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
+    TRY(ilvlm_layernorm_bwd(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
+                            b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, s));
+    // attention
+    dy = lp ? (const void*)dmid_lp : (const void*)dmid;
+    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg));
+    if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
+    else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
+    TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg));
+    return ilvlm_layernorm_bwd(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
+                               nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, s);
+}

@@ -121,6 +121,8 @@ class Engine:
         self.wgrad_streams = os.environ.get("ILVLM_WGRAD_STREAMS", "1") == "1"
         self._wg = {}
         self._wg_keep = {}      # tower stream -> tensors its companion stream still reads
+        self.composite = os.environ.get("ILVLM_COMPOSITE", "1") == "1"    # one C call per transformer block
+        self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
     @property
     def side_stream(self):
@@ -145,7 +147,10 @@ class Engine:
         self.Wf = a.views                                     # fp32 masters
         self.Wc = a.sviews if self.precision == "bf16" else a.views   # GEMM operands
         self.Gr = a.gviews
-        self.req = {n: p.requires_grad for n, p in a.named}
+        req = {n: p.requires_grad for n, p in a.named}
+        if req != getattr(self, "req", None):
+            self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots
+        self.req = req
 
     def _wgrad_stream(self):
         """companion stream of the current stream for weight-gradient GEMMs (ILVLM_WGRAD_STREAMS=0 switches it off)"""
@@ -164,6 +169,27 @@ class Engine:
             torch.cuda.current_stream().wait_stream(wg)
             # tensors freed from here on are reused by work enqueued after this join, i.e. after the weight gradients
             self._wg_keep.pop(torch.cuda.current_stream().cuda_stream, None)
+
+    def _block_desc(self, pre, E, H, causal):
+        """ilvlm_block descriptor of the transformer block with parameter prefix `pre`, or None when the composite path
+        does not apply: switched off (ILVLM_COMPOSITE=0), a GEMM profiler is attached (it times the individual launches),
+        or a LayerNorm parameter of the block is frozen."""
+        if not self.composite or ops._gemm_profiler is not None:
+            return None
+        d = self._blk.get(pre)
+        if d is None:
+            names = dict(ln1_w="ln_1.weight", ln1_b="ln_1.bias", ln2_w="ln_2.weight", ln2_b="ln_2.bias",
+                         in_w="attn.in_proj_weight", in_b="attn.in_proj_bias", out_w="attn.out_proj.weight",
+                         out_b="attn.out_proj.bias", fc_w="mlp.c_fc.weight", fc_b="mlp.c_fc.bias",
+                         proj_w="mlp.c_proj.weight", proj_b="mlp.c_proj.bias")
+            if not all(self.req[pre + names[k]] for k in ("ln1_w", "ln1_b", "ln2_w", "ln2_b")):
+                d = False
+            else:
+                params = {k: (self.Wc if k in ("in_w", "out_w", "fc_w", "proj_w") else self.Wf)[pre + n] for k, n in names.items()}
+                grads = {"g_" + k: (self.Gr[pre + n] if self.req[pre + n] else None) for k, n in names.items()}
+                d = ops.block_desc(E, H, causal, self.T, params, grads)
+            self._blk[pre] = d
+        return d or None
 
     def _mat(self, name):
         w = self.Wc[name]
@@ -204,6 +230,12 @@ class Engine:
     def block_fwd(self, x_in, pre, B, L, H, causal, save, seq=None):
         """seq: ops.PackedSeq when the rows are the valid tokens only (text tower of a training step)."""
         M, E = x_in.shape
+        desc = self._block_desc(pre, E, H, causal)
+        if desc is not None:      # one C call for the 8 kernels of the block (ilvlm_block_fwd)
+            ws = torch.empty(ops.block_saved_bytes(desc, M, B, L), dtype=torch.uint8, device=x_in.device)
+            x_out = _empty((M, E), torch.float32, x_in)
+            ops.block_fwd(desc, x_in, x_out, ws, B, L, seq)
+            return x_out, ((x_in, ws) if save else None)
         T = self.T
         Wf = self.Wf
         h1 = _empty((M, E), T, x_in); mean1 = _empty((M,), torch.float32, x_in); rstd1 = torch.empty_like(mean1)
@@ -226,6 +258,20 @@ class Engine:
     def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None):
         """dx_f32: fp32 gradient of the block output; dx_lp: the same in T (None in fp32 mode).  Returns the pair
         for the block input."""
+        if len(saved) == 2:       # saved by the composite forward: composite backward (ilvlm_block_bwd)
+            x_in, ws = saved
+            M, E = x_in.shape
+            desc = self._block_desc(pre, E, H, causal)
+            lp = self.T != torch.float32
+            din = _empty((M, E), torch.float32, x_in)
+            din_lp = _empty((M, E), self.T, x_in) if lp else None
+            scratch = torch.empty(ops.block_scratch_bytes(desc, M), dtype=torch.uint8, device=x_in.device)
+            wg = self._wgrad_stream()
+            if wg is not None:    # the scratch holds the dY operands of the weight-gradient GEMMs: alive until the join
+                self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(scratch)
+                self._wg_keep[torch.cuda.current_stream().cuda_stream].append(dx_lp if lp else dx_f32)
+            ops.block_bwd(desc, x_in, ws, dx_f32, dx_lp, din, din_lp, scratch, B, L, seq, wg)
+            return din, din_lp
         x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
         M, E = x_in.shape
         T, Wf, Gr = self.T, self.Wf, self.Gr

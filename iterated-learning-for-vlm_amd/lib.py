@@ -19,6 +19,14 @@ class GemmEpilogue(C.Structure):
                 ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp)]
 
 
+class Block(C.Structure):
+    """ilvlm_block: parameters, gradient slots and geometry of one residual attention block"""
+    _fields_ = ([(n, vp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "in_w", "out_w", "fc_w", "proj_w", "in_b", "out_b",
+                                   "fc_b", "proj_b", "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_in_w", "g_in_b", "g_out_w",
+                                   "g_out_b", "g_fc_w", "g_fc_b", "g_proj_w", "g_proj_b")] +
+                [("E", i32), ("H", i32), ("causal", i32), ("dtype", i32)])
+
+
 class AdamWHyper(C.Structure):
     _fields_ = [("lr", f32 * 16), ("weight_decay", f32 * 16), ("active", i32 * 16),
                 ("beta1", f32), ("beta2", f32), ("eps", f32), ("step", i32)]
@@ -59,6 +67,10 @@ SIGNATURES = {
     "ilvlm_clamp": [vp, f32, f32, i64, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
+    "ilvlm_block_saved_bytes": [C.POINTER(Block), i64, i32, i32],
+    "ilvlm_block_scratch_bytes": [C.POINTER(Block), i64],
+    "ilvlm_block_fwd": [C.POINTER(Block), vp, vp, vp, i64, i32, i32, i32, vp, vp],
+    "ilvlm_block_bwd": [C.POINTER(Block), vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp],
     "ilvlm_embed_packed_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_embed_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_attention_packed_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
@@ -95,7 +107,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i32
+        fn.restype = i64 if name.endswith("_bytes") else i32
     _lib = lib
     return lib
 

@@ -177,6 +177,55 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, rows, cols, dres=None
             "layernorm_bwd")
 
 
+def block_desc(E, H, causal, dtype, params, grads):
+    """ilvlm_block from tensors: params / grads are dicts keyed by the struct field names (grads: missing or None =
+    frozen)."""
+    b = L.Block()
+    for k, t in params.items():
+        setattr(b, k, t.data_ptr())
+    for k in ("g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_in_w", "g_in_b", "g_out_w", "g_out_b", "g_fc_w", "g_fc_b",
+              "g_proj_w", "g_proj_b"):
+        t = grads.get(k)
+        setattr(b, k, None if t is None else t.data_ptr())
+    b.E, b.H, b.causal, b.dtype = int(E), int(H), int(causal), _TD[dtype]
+    return b
+
+
+def block_saved_bytes(desc, rows, B, Lq):
+    n = L.load().ilvlm_block_saved_bytes(C.byref(desc), rows, B, Lq)
+    if n <= 0:
+        raise RuntimeError("ilvlm block_saved_bytes: bad arguments")
+    return n
+
+
+def block_scratch_bytes(desc, rows):
+    n = L.load().ilvlm_block_scratch_bytes(C.byref(desc), rows)
+    if n <= 0:
+        raise RuntimeError("ilvlm block_scratch_bytes: bad arguments")
+    return n
+
+
+def block_fwd(desc, x_in, x_out, saved, B, Lq, seq=None):
+    rows = x_in.shape[0]
+    _chk(x_in, "block.x_in", torch.float32, (rows, desc.E)); _chk(x_out, "block.x_out", torch.float32, (rows, desc.E))
+    _chk(saved, "block.saved", torch.uint8)
+    L.check(L.load().ilvlm_block_fwd(C.byref(desc), x_in.data_ptr(), x_out.data_ptr(), saved.data_ptr(), rows, B, Lq,
+                                     seq.cap if seq is not None else Lq, seq.offs.data_ptr() if seq is not None else None,
+                                     _stream()), "block_fwd")
+
+
+def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq, seq=None, wgrad_stream=None):
+    rows = x_in.shape[0]
+    _chk(dx_f32, "block.dx", torch.float32, (rows, desc.E)); _chk(din_f32, "block.din", torch.float32, (rows, desc.E))
+    _chk(scratch, "block.scratch", torch.uint8); _chk(saved, "block.saved", torch.uint8)
+    ws = _ln_workspace(x_in.device, desc.E)
+    L.check(L.load().ilvlm_block_bwd(C.byref(desc), x_in.data_ptr(), saved.data_ptr(), dx_f32.data_ptr(), _p(dx_lp),
+                                     din_f32.data_ptr(), _p(din_lp), scratch.data_ptr(), ws.data_ptr(), LN_WS_BLOCKS, rows,
+                                     B, Lq, seq.cap if seq is not None else Lq,
+                                     seq.offs.data_ptr() if seq is not None else None, _WGRAD_TARGET, _stream(),
+                                     None if wgrad_stream is None else wgrad_stream.cuda_stream), "block_bwd")
+
+
 class PackedSeq(object):
     """Row layout of a packed text batch (include/ilvlm_hip.h, "packed text rows"): sequence b owns rows
     [offs[b], offs[b+1]).  `lengths` is a host-side int sequence; the offsets live on the device as int32."""

@@ -285,3 +285,30 @@ def test_packed_text_rows_equal_all_positions(golden_dir, precision):
                 scale = max(float(gr.abs().max()), 1e-12)
                 err = float((o[2][n] - gr).abs().max()) / scale
                 assert err < (1e-4 if precision == "fp32" else 8e-2) or float((o[2][n] - gr).abs().max()) < 1e-7, (variant_key(v), n, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_composite_block_calls_equal_the_kernel_by_kernel_path(golden_dir, precision):
+    """ilvlm_block_fwd / _bwd issue the same kernels in the same order as the engine's one-by-one path: the forward must be
+    bit-identical, the gradients equal up to the summation order of the split-K atomics."""
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    g = np.load(os.path.join(golden_dir, "g1_fdt_step_a.npz"))
+    img = torch.from_numpy(g["images"]).cuda()
+    tok, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["pad_mask"])
+    v = FDT_VARIANTS[0]
+    outs = []
+    for composite in (True, False):
+        model = build("a", v, precision)
+        model.engine.composite = composite
+        (li, lt), _ = model(img, (tok, mask))
+        loss, _ = ClipInfoCELoss()(li, lt)
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert bool(model.engine._blk) == composite          # the path under test was really taken
+        outs.append((li.detach().cpu(), lt.detach().cpu(), {n: p.grad.detach().float().cpu().clone()
+                                                             for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for n, gr in outs[1][2].items():
+        scale = max(float(gr.abs().max()), 1e-12)
+        assert float((outs[0][2][n] - gr).abs().max()) / scale < 1e-4 or float((outs[0][2][n] - gr).abs().max()) < 1e-7, n
