@@ -291,6 +291,22 @@ __device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, in
     }
 }
 
+// Workgroup barrier of the pipelined kernels: raw s_barrier preceded by s_waitcnt lgkmcnt(0), both fenced for the compiler.
+// The raw intrinsic is neither a memory barrier for the compiler (IntrNoMem) nor does it wait for the wave's LDS traffic,
+// and MFMAs are free to sink below it together with the s_waitcnt of the fragments they consume.  A wave could thus cross
+// the end-of-K-tile barrier with fragment ds_reads still queued, a faster wave issued the next tile's DMA, and when the
+// LDS pipeline was busy (other workgroups of the CU transposing their epilogue through LDS) the DMA data overtook those
+// reads: about one launch in ten came out with a 32-row x 128-column slice short of one K-tile -- found by a full-size
+// packed-vs-dense comparison, invisible at test sizes.  Draining the LDS counter before the barrier closes the window
+// (`benchmarks/gemm_determinism.py`: 0 of 400 launches differ); it costs nothing measurable because the fragments are
+// needed by the MFMAs in front of the barrier anyway.
+#define ILVLM_WG_BARRIER()                                      \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+    } while (0)
+
 // ILVLM_GEMM_ABLATE (diagnostic builds only, `make ablate`): 1 = no fragment reads / MFMA, 2 = no operand DMA,
 // 3 = no epilogue -- what each phase of the direct-to-LDS kernel costs with the others left in place
 #ifndef ILVLM_GEMM_ABLATE
@@ -406,7 +422,10 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
                 const int row = ii * 16 + c;
                 *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * p + ii][j];
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // lanes read what OTHER lanes wrote: per thread the stores above and the loads below touch different addresses, so
+        // the compiler is free to reorder them unless told otherwise (a release fence alone lets the loads move up).  The
+        // LDS queue itself is in order.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
@@ -440,7 +459,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
                 else store4<bf16>(ep.Cb + off[k], v);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
     }
 }
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
             STAMP(q1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(q2);
-            __builtin_amdgcn_s_barrier();
+            ILVLM_WG_BARRIER();
 #ifdef ILVLM_GEMM_STAMPS
             q3 = stamp();
 #endif
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
             if (NSTAGE == 3 && t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(r1);
-            __builtin_amdgcn_s_barrier();
+            ILVLM_WG_BARRIER();
             STAMP(r2);
             STAMP_ADD(c_wait, r0, r1); STAMP_ADD(c_bar, r1, r2);
             // NSTAGE == 3: the two waves of a SIMD issue their DMA at opposite ends of the K-tile, so one wave's load
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
                 opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
             }
         }
-        if (NSTAGE == 1) __builtin_amdgcn_s_barrier();
+        if (NSTAGE == 1) ILVLM_WG_BARRIER();
         else st = st == NSTAGE - 1 ? 0 : st + 1;
 #ifdef ILVLM_GEMM_STAMPS
         STAMP(q5);
@@ -601,7 +620,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     if (acc[0][0][0] != 12345.678f) return;
 #endif
     if (SWAP) {
-        if (NSTAGE > 1) __syncthreads();             // every wave is done with the operand ring
+        // every wave must be done reading the operand tiles before any wave overwrites them with its fragments
+        __syncthreads();
         epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
     } else {
         const int g = lane >> 4, c = lane & 15;

@@ -196,3 +196,52 @@ def test_solver_with_string_captions_through_the_prefetcher(tmp_path, golden_dir
     finally:
         del os.environ["ILVLM_PREFETCH"]
     assert len(losses) == 3 and np.allclose(losses, losses2, rtol=2e-5, atol=1e-6), (losses, losses2)
+
+
+def test_full_size_step_properties():
+    """BASELINE configs[1] shapes (ViT-B/32 + FDT, per-GPU batch 256, bf16): size-independent properties of the step --
+    the two logit matrices are transposes of each other on one GPU, the loss starts near ln(B), packed text rows and all
+    positions agree, every gradient is finite, the parameters the FDT loss never reaches get none, and a few AdamW steps
+    on a fixed batch lower the loss."""
+    import math
+    import bench as B
+    from ilvlm_amd import ops
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    from ilvlm_amd.prototype.optimizer import optim_entry
+    from ilvlm_amd.prototype.utils.misc import param_group_all
+    torch.manual_seed(0)
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=B.fdt_kwargs("bf16"))).cuda().train()
+    images, tokens, pad, lens = B.synthetic_batch(256, 0, "cuda")
+    crit = ClipInfoCELoss()
+    outs = {}
+    for name, texts in (("packed", (tokens, pad, lens)), ("dense", (tokens, pad))):
+        (li, lt), _ = model(images, texts)
+        loss, _ = crit(li, lt)
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[name] = (li.detach().float().cpu(), lt.detach().float().cpu(), loss.item())
+        assert li.shape == (256, 256) and torch.allclose(li, lt.t(), rtol=1e-4, atol=1e-4)
+        assert abs(loss.item() - math.log(256)) < 0.5
+        unused = set(model.unused_parameter_names())
+        for n, p in model.named_parameters():
+            if n in unused or not p.requires_grad:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            else:
+                assert torch.isfinite(p.grad).all(), n
+    scale = float(outs["dense"][0].abs().max())
+    assert float((outs["packed"][0] - outs["dense"][0]).abs().max()) / scale < 1e-2
+    assert abs(outs["packed"][2] - outs["dense"][2]) < 1e-2 * abs(outs["dense"][2])
+    groups = param_group_all(model, B.PCONFIG)[0]
+    opt = optim_entry(dict(type="AdamW", kwargs=dict(params=groups, lr=5e-4, weight_decay=0.1, betas=[0.9, 0.98], eps=1e-8)))
+    losses = []
+    for _ in range(6):
+        (li, lt), _ = model(images, (tokens, pad, lens))
+        loss, _ = crit(li, lt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ops.clamp_(model.logit_scale.data, 3, 6)
+        losses.append(loss.item())
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0] - 0.05, losses
