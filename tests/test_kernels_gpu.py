@@ -636,3 +636,20 @@ def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, 
                 assert torch.equal(out, first), "launch %d differs from launch 0" % it
     finally:
         ops.gemm_set_variant(5)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(2048, 512, 19712, 6), (3072, 768, 12800, 3), (512, 512, 11319, 16)])
+def test_weight_gradient_gemm_at_full_size(M, N, K, split):
+    """split-K weight-gradient launches of the step's shapes, repeated: fp32 atomics make the sum order vary, the result may
+    not (same race guard as above for the accumulating form of the kernel, incl. a ragged reduction length)."""
+    ops = _ops()
+    a, b = rnd(K, M, seed=1).to(torch.bfloat16).cuda(), rnd(K, N, seed=2).to(torch.bfloat16).cuda()
+    ref = a.float().t() @ b.float()
+    rs_ref = a.float().sum(0)
+    scale = float(ref.abs().max())
+    for it in range(12):
+        out = torch.zeros(M, N, device="cuda")
+        rs = torch.zeros(M, device="cuda")
+        ops.gemm(a, b, out, trans_a=True, trans_b=True, accumulate=True, split_k=split, a_rowsum=rs)
+        assert float((out - ref).abs().max()) < 1e-3 * scale, "launch %d" % it
+        assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
