@@ -312,3 +312,39 @@ def test_composite_block_calls_equal_the_kernel_by_kernel_path(golden_dir, preci
     for n, gr in outs[1][2].items():
         scale = max(float(gr.abs().max()), 1e-12)
         assert float((outs[0][2][n] - gr).abs().max()) / scale < 1e-4 or float((outs[0][2][n] - gr).abs().max()) < 1e-7, n
+
+
+def test_real_size_vitb32_fdt_step_matches_oracle_fp32():
+    """The shipped geometry (ViT-B/32, 12 + 12 layers, 4096 x 512 codebook) at batch 16 in fp32 mode: logits, loss and a
+    sample of gradients (one per kind of kernel that produces them) against the CPU oracle on the same random weights --
+    real widths, real launch shapes, all streams on."""
+    import bench as BN
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    torch.manual_seed(1)
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=BN.fdt_kwargs("fp32")))
+    p = {k: v.detach().clone().requires_grad_(k != "visual.conv1.weight") for k, v in model.state_dict().items()}
+    B = 16
+    img = det_images(B, 224, 9)
+    tok, mask = det_tokens(B, 77, 9)
+    o = O.clip_fdt_forward(p, torch.from_numpy(img), torch.from_numpy(tok), torch.from_numpy(mask),
+                           dict(v_heads=12, t_heads=8, temperature=1000.0, att_func="sparsemax", pool="max"))
+    loss_ref, _ = O.info_nce(o["logits_i"], o["logits_t"])
+    loss_ref.backward()
+    model.cuda().train()
+    (li, lt), _ = model(torch.from_numpy(img).cuda(), (torch.from_numpy(tok), torch.from_numpy(mask)))
+    loss, _ = ClipInfoCELoss()(li, lt)
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert relerr(li, o["logits_i"].detach().numpy()) < 1e-3 and relerr(lt, o["logits_t"].detach().numpy()) < 1e-3
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    got = dict(model.named_parameters())
+    for name in ("space_dict", "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.11.mlp.c_fc.bias",
+                 "visual.transformer.resblocks.5.ln_2.weight", "visual.positional_embedding", "visual.class_embedding",
+                 "encode_text.token_embedding.weight", "encode_text.positional_embedding",
+                 "encode_text.transformer.resblocks.0.mlp.c_proj.weight", "encode_text.transformer.resblocks.11.ln_1.bias",
+                 "encode_text.ln_final.weight", "img_query_model.q_map.1.weight", "txt_query_model.q_map.4.bias", "logit_scale"):
+        ref = p[name].grad
+        err = float((got[name].grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err < 2e-3 or float((got[name].grad.cpu() - ref).abs().max()) < 2e-6, (name, err)
