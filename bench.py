@@ -281,7 +281,7 @@ def main():
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "towers": "serial" if args.serial_towers else "concurrent (2 HIP streams)",
+            "towers": "serial" if args.serial_towers else "concurrent (one HIP stream per tower + a weight-gradient companion stream each)",
             "config": {"workload": "example/clip_fdt %s + FDT codebook (4096x512, sparsemax, max-pool, T=1000), "
                                    "%s compute / fp32 master weights, full train step incl. AdamW" % (
                                        "ViT-B/32" if args.model == "vitb32" else "ViT-L/14 (BASELINE configs[3])", args.precision),
