@@ -7,6 +7,9 @@
 //   fp32 path : 64x64x16 tile on v_mfma_f32_16x16x4_f32 (bit-exact fp32 FMA chain) for the fp32
 //               parity mode and the small precision-critical products (att@sd, logits).
 // Replaces F.linear / matmul call sites listed in include/ilvlm_hip.h.
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -377,8 +380,8 @@ struct DmaOperand {
         tile_off = !TR ? r0 * ld * 2 : r0 * 2;
         k_step = !TR ? BKT * 2 : BKT * ld * 2;
     }
-    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave) const {
-        const int soff = tile_off + t * k_step;
+    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
+        const int soff = tile_off + t * k_step + extra;
 #pragma unroll
         for (int j = 0; j < NLOAD; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
@@ -393,74 +396,102 @@ struct DmaOperand {
 // slice of the (now idle) operand LDS: afterwards lane l owns row (l>>4) of a 4-row group and columns 4*(l&15)..+3, and
 // every load / store instruction of the epilogue covers 4 rows x 256 (fp32) / 128 (bf16) contiguous bytes -- a quarter
 // of the requests.  Two passes of 32 rows; all loads of a half-pass are issued before its first store.
-template <int TI, int TJ>
-__device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
-                                              float alpha, unsigned char* wlds) {
-    const ilvlm_gemm_epilogue& e = ep.e;
-    const int g = lane >> 4, c = lane & 15;
-    const int npre = (e.residual != nullptr) + (e.rowbias != nullptr) +
-                     (e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD);
-    const bool fast = TJ == 4 && (TI % 2) == 0 && ep.vec_ok && !e.accumulate && npre <= 1 && m_base + TI * 16 <= ep.M &&
-                      n_base + TJ * 16 <= ep.N;
-    if (!fast) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) epilogue4<bf16>(ep, m_base + i * 16 + c, n_base + j * 16 + 4 * g, acc[i][j], alpha);
-        return;
-    }
-    const int n = n_base + 4 * c;                   // this lane's columns after the transpose
-    const f32x4 bias = e.bias ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
-    const bool bwd = e.act == ILVLM_ACT_QUICKGELU_BWD || e.act == ILVLM_ACT_GELU_ERF_BWD;
-#pragma unroll
-    for (int p = 0; p < TI / 2; ++p) {
-        // fragments of row tiles 2p, 2p+1 -> [32 rows][64 fp32] image, 16-byte chunk index XOR (row & 15)
+// Epilogue modes.  The epilogue runs once per tile, so its instruction footprint matters as much as its instruction
+// count: with every variant inlined behind run-time branches and all loops unrolled the 256x256 kernel was 196 KB of
+// code against a 64 KB instruction cache, and a workgroup that owns its CU stalled on instruction fetch for ~27 us per
+// tile (K-scaling, benchmarks/p8_scaling.py).  The variant is therefore a template parameter picked by one switch, and
+// the row-group loop is a real loop: the executed path of a tile is a few KB.
+enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, EPI_GELU_BWD };
+
+// one pass (32 rows: row tiles 2P, 2P+1) of epilogue_tile; the pass index is a template parameter so that the accumulator
+// array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
+template <int MODE, int TI, int TJ, int P>
+__device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n, int lane, float alpha,
+                                              unsigned char* wlds, f32x4 bias) {
+    if constexpr (P < TI / 2) {
+        const ilvlm_gemm_epilogue& e = ep.e;
+        const int g = lane >> 4, c = lane & 15;
+        // fragments of row tiles 2P, 2P+1 -> [32 rows][64 fp32] image, 16-byte chunk index XOR (row & 15)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int row = ii * 16 + c;
-                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * p + ii][j];
+                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * P + ii][j];
             }
         // lanes read what OTHER lanes wrote: per thread the stores above and the loads below touch different addresses, so
         // the compiler is free to reorder them unless told otherwise (a release fence alone lets the loads move up).  The
         // LDS queue itself is in order.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
-            f32x4 pre[4];
-            long off[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int m = m_base + p * 32 + h * 16 + 4 * k + g;
-                off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
-                if (e.residual) pre[k] = *(const f32x4*)(e.residual + off[k]);
-                else if (e.rowbias) pre[k] = *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * ep.N + n);
-                else if (bwd) pre[k] = load4<bf16>((const bf16*)e.aux + off[k]);
+        if constexpr (MODE == EPI_GENERIC) {
+            // ragged tile, unaligned operands or a rare epilogue (row-indexed bias): one bounds-checked call per 4-row group
+#pragma unroll 1
+            for (int hk = 0; hk < 8; ++hk) {
+                const int row = 4 * hk + g;
+                const f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
+                epilogue4<bf16>(ep, m_base + P * 32 + row, n, v, alpha);
             }
+        } else {
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {            // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
+                f32x4 pre[4];
+                long off[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = h * 16 + 4 * k + g;
-                f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
-                v = v * alpha + bias;
-                if (e.rowbias) v += pre[k];
-                if (e.act == ILVLM_ACT_QUICKGELU || e.act == ILVLM_ACT_GELU_ERF) {
-                    store4<bf16>((bf16*)e.aux + off[k], v);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = e.act == ILVLM_ACT_QUICKGELU ? quick_gelu(v[q]) : gelu_erf(v[q]);
-                } else if (bwd) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] *= e.act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(pre[k][q]) : gelu_erf_grad(pre[k][q]);
+                for (int k = 0; k < 4; ++k) {        // every load of the half-pass before its first store (vmcnt counts both)
+                    const int m = m_base + P * 32 + h * 16 + 4 * k + g;
+                    off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
+                    if constexpr (MODE == EPI_RES) pre[k] = *(const f32x4*)(e.residual + off[k]);
+                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) pre[k] = load4<bf16>((const bf16*)e.aux + off[k]);
                 }
-                if (e.residual) v += pre[k];
-                if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
-                else store4<bf16>(ep.Cb + off[k], v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = h * 16 + 4 * k + g;
+                    f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
+                    v = v * alpha + bias;
+                    if constexpr (MODE == EPI_QGELU || MODE == EPI_GELU) {
+                        store4<bf16>((bf16*)e.aux + off[k], v);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = MODE == EPI_QGELU ? quick_gelu(v[q]) : gelu_erf(v[q]);
+                    }
+                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] *= MODE == EPI_QGELU_BWD ? quick_gelu_grad(pre[k][q]) : gelu_erf_grad(pre[k][q]);
+                    }
+                    if constexpr (MODE == EPI_RES) v += pre[k];
+                    if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
+                    else store4<bf16>(ep.Cb + off[k], v);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
+        epilogue_pass<MODE, TI, TJ, P + 1>(ep, acc, m_base, n, lane, alpha, wlds, bias);
+    }
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
+                                              float alpha, unsigned char* wlds) {
+    const ilvlm_gemm_epilogue& e = ep.e;
+    static_assert(TJ == 4 && (TI % 2) == 0, "64-column wave tiles, row tiles in pairs");
+    const bool whole = ep.vec_ok && !e.accumulate && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
+    int mode = EPI_GENERIC;
+    if (whole && !e.rowbias) {
+        if (e.act == ILVLM_ACT_NONE) mode = e.residual ? EPI_RES : EPI_PLAIN;
+        else if (!e.residual) mode = EPI_QGELU + (e.act - ILVLM_ACT_QUICKGELU);
+    }
+    const int n = n_base + 4 * (lane & 15);          // this lane's columns after the transpose
+    const f32x4 bias = (mode != EPI_GENERIC && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
+    switch (mode) {
+        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        default: epilogue_pass<EPI_GENERIC, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
     }
 }
 
@@ -660,6 +691,264 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 }
 
 // =====================================================================================
+// bf16 "phased" kernel: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), one workgroup per CU, 128 KiB of LDS =
+// two K-tile buffers of four 16 KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255).
+//
+// A 256x256 tile needs half the L2->LDS bytes per FLOP of the 128x128 kernel above (whose operand DMA and MFMA time
+// per K-tile are equal at the CU's 64 B/clk, so neither can be hidden behind the other).  The K-tile is cut into four
+// phases of {LOAD section: fragment ds_reads of one quadrant's operands + the DMA of one half-tile of a later K-tile;
+// COMPUTE section: 16 MFMAs = one 64x32 quadrant of the wave's 128x64 output x K = 64}, every section closed by a
+// workgroup barrier.  Waves 4-7 (the second wave of every SIMD) run one section behind waves 0-3, so on each SIMD one
+// wave's MFMAs cover the other's LDS reads and DMA issue.  DMA stays in flight across barriers behind a counted vmcnt.
+//
+// Schedule of K-tile t (buffer t & 1), wave (wr, wc): A half wr, B half wc >> 1, columns 64 (wc & 1) .. +63
+//   L1  read A rows 0-63 (8) + B cols 0-31 (4)     C1  acc[0..3][0..1], DMA A0(t+1) between the MFMAs
+//   L2  read B cols 32-63 (4)                      C2  acc[0..3][2..3], DMA A1(t+1)
+//   L3  read A rows 64-127 (8)                     C3  acc[4..7][2..3], DMA B0(t+2)
+//   L4  vmcnt: K-tile t+1 landed                   C4  acc[4..7][0..1], DMA B1(t+2)   (B cols 0-31 kept in registers)
+// Hazards, counted in sections (a wave of the late group runs section s one barrier interval after the early group):
+//   RAW  every wave retires its own pieces of K-tile t+1 with the vmcnt of L4(t); the first read of that buffer is in
+//        L1(t+1), two sections later, i.e. behind a barrier that every wave passed after its wait.
+//   WAR  a half-tile is re-filled two or more sections after the section that read it last, and every LOAD section drains
+//        its own ds_reads (lgkmcnt(0)) in front of its closing barrier: B halves are read last in L2 and re-filled from
+//        C3 on, A halves are read last in L3 and re-filled in C1 / C2 of the next K-tile.
+// =====================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ILVLM_SECTION_END()                                     \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        __builtin_amdgcn_s_barrier();                           \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+
+template <bool TA, bool TB, bool ACC, int PB>
+struct P8Tile {
+    typedef DmaOperand<TA, 128, 512, 64> OpA;
+    typedef DmaOperand<TB, 128, 512, 64> OpB;
+    static constexpr int HALF = 16384, BUF = 65536;
+
+    // 16 MFMAs of one quadrant; the DMA of one half-tile is issued between them (an LDS-DMA instruction costs the issuing
+    // wave 100-185 cycles next to LDS reads but ~60 among MFMAs, which keep executing while it issues)
+    template <class Op>
+    static __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const int i0, const int j0, bf16x8 (&fa)[4][2],
+                                                    bf16x8 (&fb)[2][2], bool dma, const Op& op, int tile_t,
+                                                    unsigned char* dst, int wave, int extra) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[i0 + i][j0 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma) op.issue(tile_t, dst, wave, extra);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][1], acc[i0 + i][j0 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // one K-tile (t = index within this workgroup's K range, nt = their number)
+    static __device__ __forceinline__ void run(unsigned char* smem, const OpA& opa, const OpB& opb, int a_half, int b_half,
+                                               int t, int nt, int t_begin, int wave, int wr, int wc, int lane,
+                                               f32x4 (&acc)[8][4], f32x4 (&accb)[2], bool rowsum) {
+        unsigned char* cur = smem + PB * BUF;
+        unsigned char* nxt = smem + (PB ^ 1) * BUF;
+        const unsigned char* aT = cur + wr * HALF;
+        const unsigned char* bT = cur + 2 * HALF + (wc >> 1) * HALF;
+        const int bcol = (wc & 1) * 64;
+        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+        bf16x8 fa[4][2], fbl[2][2], fbr[2][2];
+        // ---- L1
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fbl[j][ks] = p8_frag<TB, 128, 64>(bT, bcol + j * 16, ks * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = p8_frag<TA, 128, 64>(aT, i * 16, ks * 32, lane);
+        ILVLM_SECTION_END();
+        // ---- C1
+        quadrant(acc, 0, 0, fa, fbl, more1, opa, t_begin + t + 1, nxt, wave, 0);
+        if (ACC && rowsum) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
+                accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[0], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- L2
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fbr[j][ks] = p8_frag<TB, 128, 64>(bT, bcol + 32 + j * 16, ks * 32, lane);
+        ILVLM_SECTION_END();
+        // ---- C2
+        quadrant(acc, 0, 2, fa, fbr, more1, opa, t_begin + t + 1, nxt + HALF, wave, a_half);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- L3
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = p8_frag<TA, 128, 64>(aT, 64 + i * 16, ks * 32, lane);
+        ILVLM_SECTION_END();
+        // ---- C3
+        quadrant(acc, 4, 2, fa, fbr, more2, opb, t_begin + t + 2, cur + 2 * HALF, wave, 0);
+        if (ACC && rowsum) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
+                accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- L4: every piece of K-tile t+1 this wave issued has landed (B0(t+2), issued in C3, may still be in flight)
+        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OpB::NLOAD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ILVLM_SECTION_END();
+        // ---- C4
+        quadrant(acc, 4, 0, fa, fbl, more2, opb, t_begin + t + 2, cur + 3 * HALF, wave, b_half);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+// accumulate epilogue of the phased kernel: fragments (C^T orientation: lane owns row (l & 15), 4 consecutive columns) are
+// transposed through a wave-private 8 KiB LDS image so that every atomic wave-instruction covers 256 contiguous bytes
+// of one output row (the shape global float atomics run at full rate with)
+template <int TI, int TJ, int P = 0>
+__device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
+                                                  float alpha, unsigned char* wlds) {
+    static_assert(TJ == 4 && TI % 2 == 0, "64-column wave tile");
+    if constexpr (P < TI / 2) {
+        const int g = lane >> 4, c = lane & 15;
+        const int n = n_base + lane;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int row = ii * 16 + c;
+                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * P + ii][j];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (m_base + P * 32 < ep.M) {
+#pragma unroll 4
+            for (int r = 0; r < 32; ++r) {
+                const int m = m_base + P * 32 + r;
+                const float v = *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
+                if (m < ep.M && n < ep.N)
+                    atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, v * alpha);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_acc_tile<TI, TJ, P + 1>(ep, acc, m_base, n_base, lane, alpha, wlds);
+    }
+}
+#endif
+
+template <bool TA, bool TB, bool ACC>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                              int ldb, int K, int tiles_m, int tiles_n, int split_k,
+                                                              EpiArgs ep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef DmaOperand<TA, 128, 512, 64> OpA;
+    typedef DmaOperand<TB, 128, 512, 64> OpB;
+    constexpr int HALF = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nwg = tiles_m * tiles_n * split_k;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int tn = wg % tiles_n; wg /= tiles_n;
+    int z, tm;
+    if (ACC) { tm = wg % tiles_m; z = wg / tiles_m; }       // K-slice major (see gemm_bf16_dma_kernel)
+    else { z = wg % split_k; tm = wg / split_k; }
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nt_total = (K + 63) / 64;
+    const int per = (nt_total + split_k - 1) / split_k;
+    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+
+    OpA opa; OpB opb;
+    opa.init(A, lda, m0, ep.M, K, wave, lane);
+    opb.init(B, ldb, n0, ep.N, K, wave, lane);
+    const int a_half = TA ? 256 : 128 * lda * 2;      // byte offset of operand rows 128.. within the tile
+    const int b_half = TB ? 256 : 128 * ldb * 2;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    f32x4 accb[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+    const bool rowsum = ACC && ep.e.a_rowsum != nullptr && tn == 0;
+
+    // prologue: K-tile 0 complete, B halves of K-tile 1
+    opa.issue(t_begin, smem_raw, wave, 0);
+    opa.issue(t_begin, smem_raw + HALF, wave, a_half);
+    opb.issue(t_begin, smem_raw + 2 * HALF, wave, 0);
+    opb.issue(t_begin, smem_raw + 3 * HALF, wave, b_half);
+    if (nt > 1) {
+        opb.issue(t_begin + 1, smem_raw + 65536 + 2 * HALF, wave, 0);
+        opb.issue(t_begin + 1, smem_raw + 65536 + 3 * HALF, wave, b_half);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OpB::NLOAD) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {                                     // the second wave of every SIMD runs one section behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int t = 0; t < nt; t += 2) {
+        P8Tile<TA, TB, ACC, 0>::run(smem_raw, opa, opb, a_half, b_half, t, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
+        if (t + 1 < nt)
+            P8Tile<TA, TB, ACC, 1>::run(smem_raw, opa, opb, a_half, b_half, t + 1, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
+    }
+    if (wr == 0) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    __syncthreads();            // every wave is done with the operand tiles before the fragments go through the same LDS
+    if (!ACC) {
+        epilogue_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+    } else {
+        epilogue_acc_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+        if (rowsum && lane < 16) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = mw + (h * 4 + wc) * 16 + lane;
+                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[h][0]);
+            }
+        }
+    }
+#endif
+}
+
+// =====================================================================================
 // fp32 kernel: 64x64x16 tile, 4 waves (2x2), each 32x32 = 2x2 tiles of 16x16x4
 // =====================================================================================
 constexpr int FM = 64, FN = 64, FK = 16, FLD = 68;
@@ -753,12 +1042,10 @@ template <bool TA, bool TB, bool SWAP>
 int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
                 hipStream_t s) {
     auto kern = gemm_bf16_kernel<TA, TB, SWAP>;
-    static bool attr_set = false;   // idempotent; a benign race sets it twice
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(256), GEMM_LDS_BYTES, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16");
     return ILVLM_OK;
@@ -770,15 +1057,27 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     // operand ring; the SWAP epilogue transposes through 8 KiB per wave of the same allocation
     constexpr int ring = NSTAGE * (DBM + DBN) * BKT * 2, epi = SWAP ? WM * WN * 8192 : 0;
     constexpr int bytes = ring > epi ? ring : epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) ILVLM_FAIL((int)e, "gemm_bf16_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_dma: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     const int tm = ceil_div(M, DBM), tn = ceil_div(N, DBN);
     hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(64 * WM * WN), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16_dma");
+    return ILVLM_OK;
+}
+
+template <bool TA, bool TB, bool ACC>
+int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_p8_kernel<TA, TB, ACC>;
+    constexpr int bytes = 131072;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_p8: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_p8");
     return ILVLM_OK;
 }
 
@@ -798,7 +1097,7 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 // 0 = register-staged general kernel only; 5 = direct-to-LDS 128x128 single stage (default: fastest inside the step);
 // 6 = 64x128 tiles where the A operand is K-contiguous; 7 = direct-to-LDS 256x128, 8 waves, 3-stage ring.  (Round-1 exploration also
 // measured global_load_lds addressing, double buffering, 256x256 and BK=32 variants -- all slower; see DESIGN.md.)
-int g_gemm_variant = 5;
+std::atomic<int> g_gemm_variant{5};
 
 }  // namespace
 
@@ -842,12 +1141,23 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bf16* a = (const bf16*)A;
         const bf16* b = (const bf16*)B;
         const bool swap = !epi->accumulate;
-        const int variant = g_gemm_variant;
+        const int variant = g_gemm_variant.load(std::memory_order_relaxed);
         // K-contiguous operands need whole K-tiles (a partial one would run into the next row); when both operands are
         // K-strided (weight gradients: the contraction runs over token rows) the k-rows past K lie beyond the buffer
         // descriptors' extent and read as zeros, so any K works -- the packed text rows need exactly that.
         const bool fast = variant != 0 && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
+        // 8 = 256x256 phased kernel (one workgroup per CU): the tall GEMMs of the towers
+        if (fast && variant == 8 && M >= 256 && N >= 256) {
+#define ILVLM_P8(TA, TB)                                                                                 \
+    return swap ? launch_p8<TA, TB, false>(a, lda, b, ldb, K, M, N, split_k, ep, s)                      \
+                : launch_p8<TA, TB, true>(a, lda, b, ldb, K, M, N, split_k, ep, s)
+            if (!trans_a && !trans_b) { ILVLM_P8(false, false); }
+            if (!trans_a && trans_b) { ILVLM_P8(false, true); }
+            if (trans_a && !trans_b) { ILVLM_P8(true, false); }
+            ILVLM_P8(true, true);
+#undef ILVLM_P8
+        }
         if (fast) {
             // 5 (default) = 128x128 / 4 waves / 1 stage (4 workgroups per CU); 7 = 256x128 / 8 waves / 3-stage ring;
             // 6 = 64x128 tiles (K-contiguous A only).  6 is 3..27 % faster in isolation on launches that leave most
@@ -894,8 +1204,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 7), "gemm_set_variant: 0, 5, 6 or 7");
-    g_gemm_variant = variant;
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 8), "gemm_set_variant: 0, 5, 6, 7 or 8");
+    g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }
 

@@ -22,6 +22,38 @@ import torch.nn.functional as F
 
 LN_EPS = 1e-5
 
+# --------------------------------------------------------------------------------------
+# operand-rounding control.  By default Q is the identity and this file is the fp32 restatement.
+# Tests that allow the bf16 HIP path more than the 1e-2 of north_star must show that the excess is
+# the dtype's and not a kernel's: `with rounding(bf16_ste): ...` re-runs the SAME oracle with every
+# matrix-product operand (weights, GEMM / attention inputs, softmax probabilities, the stored word
+# features) rounded to bf16 while sums stay fp32 -- the storage points of the bf16 mode listed in
+# DESIGN.md section 3 -- and the test compares the two errors.
+# --------------------------------------------------------------------------------------
+_ROUND = None
+
+
+def Q(t):
+    return t if _ROUND is None else _ROUND(t)
+
+
+def bf16_ste(t):
+    """round-to-nearest-even to bf16, gradient passed straight through"""
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+class rounding(object):
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _ROUND
+        self.prev, _ROUND = _ROUND, self.fn
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = self.prev
+
 
 # --------------------------------------------------------------------------------------
 # elementwise / row ops
@@ -44,7 +76,7 @@ def gelu_erf(x):
 
 
 def linear(x, w, b=None):
-    y = x @ w.t()
+    y = Q(x) @ Q(w).t()
     return y if b is None else y + b
 
 
@@ -66,7 +98,7 @@ def mha(x, in_w, in_b, out_w, out_b, heads, causal):
     """
     B, L, E = x.shape
     hd = E // heads
-    qkv = linear(x, in_w, in_b)
+    qkv = Q(linear(x, in_w, in_b))
     q, k, v = qkv.split(E, dim=-1)
     q = q.reshape(B, L, heads, hd).transpose(1, 2) * math.sqrt(1.0 / hd)
     k = k.reshape(B, L, heads, hd).transpose(1, 2)
@@ -75,7 +107,7 @@ def mha(x, in_w, in_b, out_w, out_b, heads, causal):
     if causal:
         s = s + causal_mask(L, s.dtype)
     p = torch.softmax(s, dim=-1)
-    o = (p @ v).transpose(1, 2).reshape(B, L, E)
+    o = (Q(p) @ v).transpose(1, 2).reshape(B, L, E)
     return linear(o, out_w, out_b)
 
 
@@ -103,7 +135,7 @@ def vit_forward(images, p, heads, pre="visual."):
     """
     w = p[pre + "conv1.weight"]
     patch = w.shape[-1]
-    x = F.conv2d(images, w, stride=patch)                      # [B,W,g,g]
+    x = F.conv2d(Q(images), Q(w), stride=patch)                # [B,W,g,g]
     B, W = x.shape[0], x.shape[1]
     x = x.reshape(B, W, -1).permute(0, 2, 1)                   # [B,P,W]
     cls = p[pre + "class_embedding"].reshape(1, 1, W).expand(B, 1, W)
@@ -126,9 +158,9 @@ def text_forward(tokens, p, heads, pre="encode_text."):
     for i in range(n_layers(p, pre)):
         x = resblock(x, p, pre + "transformer.resblocks.%d." % i, heads, causal=True)
     x = layer_norm(x, p[pre + "ln_final.weight"], p[pre + "ln_final.bias"])
-    words = x
+    words = Q(x)                       # the word features are stored in the compute dtype; the pooled head stays fp32
     feat = x[torch.arange(x.shape[0]), tokens.argmax(dim=-1)]
-    out = linear(feat, p[pre + "text_projection.weight"], p[pre + "text_projection.bias"])
+    out = feat @ p[pre + "text_projection.weight"].t() + p[pre + "text_projection.bias"]
     return out, words, feat
 
 
@@ -164,8 +196,8 @@ def query_model(ft, sd, p, pre, temperature, att_func, pool, mask=None):
     (clip_fdt.py:122-127), they are not excluded from the pooling.
     Returns dict(q, pooled, att_w, att_ft).
     """
-    q = q_map(ft, p, pre)
-    dot = q @ sd.t()
+    q = Q(q_map(ft, p, pre))
+    dot = q @ Q(sd).t()
     dot = dot / math.sqrt(sd.shape[1])
     if mask is not None:
         dot = dot * ((mask == 0) * 1).unsqueeze(-1)
