@@ -3,8 +3,8 @@ usage: python benchmarks/gemm_ablate.py          -> runs itself once per library
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = {"": "full", "_abl1": "no MFMA/ds_read", "_abl2": "no operand DMA", "_abl3": "no epilogue"}
-SHAPES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1), ("fc2.fwd", 0, 0, 12800, 768, 3072, False, 1),
+NAMES = {"": "full", "_abl1": "no MFMA/ds_read", "_abl2": "no operand DMA", "_abl3": "no epilogue", "_abl4": "no MFMA", "_abl5": "no ds_read"}
+SHAPES = [("big.fwd", 0, 0, 12800, 3072, 3072, False, 1), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1), ("fc2.fwd", 0, 0, 12800, 768, 3072, False, 1),
           ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1), ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3),
           ("qkv.fwd", 0, 0, 12800, 2304, 768, False, 1), ("txt.fc.fwd", 0, 0, 19712, 2048, 512, False, 1),
           ("qkv.wgrad", 1, 1, 2304, 768, 12800, True, 4), ("out.wgrad", 1, 1, 768, 768, 12800, True, 11),
@@ -16,6 +16,7 @@ def child(suffix):
     import ilvlm_amd.lib as L
     L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip%s.so" % suffix)
     from ilvlm_amd import ops
+    ops.gemm_set_variant(int(os.environ.get("ABL_VARIANT", "5")))
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:
         a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
         b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)

@@ -168,6 +168,9 @@ int ilvlm_topk_accuracy(const float* logits, int B, int Bg, int label_offset, in
 int ilvlm_colsum(const void* x, int dtype, float* out, long rows, int cols, int ld, void* stream);
 /* dst (dtype) = src (fp32): bf16 shadow of the fp32 master weights */
 int ilvlm_cast_f32(const float* src, void* dst, int dst_dtype, long n, void* stream);
+/* dst (fp32) = src (bf16): a bf16 gradient bucket back into the fp32 gradient arena after the data-parallel mean
+ * (the reference reduces fp32 buckets inside torch DDP, prototype/utils/torch_ddp_dist.py:65) */
+int ilvlm_cast_to_f32(const void* src, int src_dtype, float* dst, long n, void* stream);
 /* y = a * x (fp32, in place allowed) */
 int ilvlm_scale(const float* x, float* y, float a, long n, void* stream);
 /* y = a[0] * x with the scalar on the device (upstream gradient of the loss, loss.py:46 / train_solver.py:420) */

@@ -311,7 +311,8 @@ __device__ __forceinline__ bf16x8 p8_frag(const unsigned char* tile, int r16, in
     } while (0)
 
 // ILVLM_GEMM_ABLATE (diagnostic builds only, `make ablate`): 1 = no fragment reads / MFMA, 2 = no operand DMA,
-// 3 = no epilogue -- what each phase of the direct-to-LDS kernel costs with the others left in place
+// 3 = no epilogue, 4 = no MFMA (fragment reads kept), 5 = no fragment reads (MFMA kept; phased kernel only) -- what each
+// phase of the direct-to-LDS kernels costs with the others left in place
 #ifndef ILVLM_GEMM_ABLATE
 #define ILVLM_GEMM_ABLATE 0
 #endif
@@ -735,19 +736,30 @@ struct P8Tile {
                                                     bf16x8 (&fb)[2][2], bool dma, const Op& op, int tile_t,
                                                     unsigned char* dst, int wave, int extra) {
         __builtin_amdgcn_s_setprio(1);
+#if ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[j][0]), "v"(fb[j][1]));
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[i0 + i][j0 + j], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#if ILVLM_GEMM_ABLATE != 2
         if (dma) op.issue(tile_t, dst, wave, extra);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#if !(ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 4)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][1], acc[i0 + i][j0 + j], 0, 0, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
     }
 
@@ -763,15 +775,20 @@ struct P8Tile {
         const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
         const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
         bf16x8 fa[4][2], fbl[2][2], fbr[2][2];
+#if ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 5
+#define P8_FRAG(TR, tile, r16, k32) ones
+#else
+#define P8_FRAG(TR, tile, r16, k32) p8_frag<TR, 128, 64>(tile, r16, k32, lane)
+#endif
         // ---- L1
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbl[j][ks] = p8_frag<TB, 128, 64>(bT, bcol + j * 16, ks * 32, lane);
+            for (int ks = 0; ks < 2; ++ks) fbl[j][ks] = P8_FRAG(TB, bT, bcol + j * 16, ks * 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = p8_frag<TA, 128, 64>(aT, i * 16, ks * 32, lane);
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, i * 16, ks * 32);
         ILVLM_SECTION_END();
         // ---- C1
         quadrant(acc, 0, 0, fa, fbl, more1, opa, t_begin + t + 1, nxt, wave, 0);
@@ -789,7 +806,7 @@ struct P8Tile {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbr[j][ks] = p8_frag<TB, 128, 64>(bT, bcol + 32 + j * 16, ks * 32, lane);
+            for (int ks = 0; ks < 2; ++ks) fbr[j][ks] = P8_FRAG(TB, bT, bcol + 32 + j * 16, ks * 32);
         ILVLM_SECTION_END();
         // ---- C2
         quadrant(acc, 0, 2, fa, fbr, more1, opa, t_begin + t + 1, nxt + HALF, wave, a_half);
@@ -800,7 +817,7 @@ struct P8Tile {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = p8_frag<TA, 128, 64>(aT, 64 + i * 16, ks * 32, lane);
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, 64 + i * 16, ks * 32);
         ILVLM_SECTION_END();
         // ---- C3
         quadrant(acc, 4, 2, fa, fbr, more2, opb, t_begin + t + 2, cur + 2 * HALF, wave, 0);
@@ -933,6 +950,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const bf16* __rest
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     __syncthreads();            // every wave is done with the operand tiles before the fragments go through the same LDS
+#if ILVLM_GEMM_ABLATE == 3
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     if (!ACC) {
         epilogue_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
     } else {

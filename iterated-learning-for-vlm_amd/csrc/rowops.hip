@@ -354,6 +354,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
         for (long j = i; j < n; ++j) dst[j] = from_f<T>(src[j]);
 }
 
+// dst (fp32) = src (bf16): bf16 gradient buckets back into the fp32 gradient arena after the all-reduce
+__global__ __launch_bounds__(256) void widen_kernel(const bf16* __restrict__ src, float* __restrict__ dst, long n) {
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 1024;
+    for (; i + 4 <= n; i += stride) *(f32x4*)(dst + i) = load4<bf16>(src + i);
+    if (i < n && i + 4 > n)
+        for (long j = i; j < n; ++j) dst[j] = (float)src[j];
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, float a, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a * x[i];
 }
@@ -597,6 +606,14 @@ extern "C" int ilvlm_cast_f32(const float* src, void* dst, int dst_dtype, long n
     else if (dst_dtype == ILVLM_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, S_, src, (float*)dst, n);
     else ILVLM_FAIL(ILVLM_ERR_ARG, "cast_f32: bad dtype %d", dst_dtype);
     ILVLM_LAUNCH_CHECK("cast_f32");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_cast_to_f32(const void* src, int src_dtype, float* dst, long n, void* stream) {
+    ILVLM_REQUIRE(src && dst && n > 0, "cast_to_f32: bad args");
+    ILVLM_REQUIRE(src_dtype == ILVLM_BF16, "cast_to_f32: source must be bf16 (got %d)", src_dtype);
+    ILVLM_REQUIRE(((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 16) == 0, "cast_to_f32: 8 / 16-byte alignment required");
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_1d(n, 1024, 4096)), dim3(256), 0, S_, (const bf16*)src, dst, n);
+    ILVLM_LAUNCH_CHECK("cast_to_f32");
     return ILVLM_OK;
 }
 extern "C" int ilvlm_scale(const float* x, float* y, float a, long n, void* stream) {

@@ -208,7 +208,9 @@ class Engine:
             # the operands must outlive the launch: the saved activation x does (the autograd node holds it until backward
             # returns, after join_wgrad); dy is kept referenced until the join instead of paying record_stream's
             # allocator events
-            self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(dy)
+            keep = self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, [])
+            keep.append(dy)
+            keep.append(x)       # x may be a temporary of the caller (the un-padded patch rows of a trainable conv1)
             ops._stream_override = wg.cuda_stream          # cheaper than entering a torch stream context per GEMM
         try:
             if self.req[wname]:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ilvlm_topk_accuracy": [vp, i32, i32, i32, i32, vp, vp],
     "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
     "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
+    "ilvlm_cast_to_f32": [vp, i32, vp, i64, vp],
     "ilvlm_scale": [vp, vp, f32, i64, vp],
     "ilvlm_scale_dev": [vp, vp, vp, i64, vp],
     "ilvlm_add_inplace": [vp, vp, i64, vp],

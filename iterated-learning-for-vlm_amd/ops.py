@@ -53,16 +53,32 @@ def selftest_fragments():
 
 # ---------------------------------------------------------------------------------------------
 class GemmProfiler:
-    """Brackets every bf16 GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+    """Brackets every bf16 GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  `ms` is the sum of
+    the launch durations; `union_ms` the time during which at least one of them was running (they overlap when the towers
+    run on their own streams), measured against a base event recorded when the profiler was created."""
 
     def __init__(self):
         self.records = []     # (start_event, end_event, flops, algorithmic bytes)
+        self.f32_flops = 0.0  # fp32 GEMM launches (not timed): att_w @ sd, logits and their gradients
+        self.base = torch.cuda.Event(enable_timing=True)
+        self.base.record()
 
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        return dict(launches=len(self.records), ms=ms, flops=float(sum(r[2] for r in self.records)),
-                    bytes=float(sum(r[3] for r in self.records)))
+        spans = sorted((self.base.elapsed_time(r[0]), self.base.elapsed_time(r[1])) for r in self.records)
+        union, cur_a, cur_b = 0.0, None, None
+        for a, b in spans:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None:
+                    union += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None:
+            union += cur_b - cur_a
+        return dict(launches=len(self.records), ms=ms, union_ms=union, flops=float(sum(r[2] for r in self.records)),
+                    bytes=float(sum(r[3] for r in self.records)), f32_flops=self.f32_flops)
 
 
 _gemm_profiler = None
@@ -110,13 +126,17 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
     epi = GemmEpilogue(_p(bias), _p(rowbias), _p(residual), _p(aux), _p(alpha_ptr), float(alpha), int(act), dt(out),
                        int(bool(accumulate)), int(out_group), int(out_skip), _p(a_rowsum))
     prof = _gemm_profiler if (_gemm_profiler is not None and a.dtype == torch.bfloat16) else None
+    if _gemm_profiler is not None and prof is None:
+        _gemm_profiler.f32_flops += 2.0 * m * n * k
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        # the events go on the stream the kernel is launched on (a weight-gradient GEMM runs on the companion stream)
+        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        ev0.record(est)
     L.check(L.load().ilvlm_gemm(dt(a), int(trans_a), int(trans_b), m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb,
                                 out.data_ptr(), ldc, C.byref(epi), int(split_k), _stream()), "gemm")
     if prof is not None:
-        ev1.record()
+        ev1.record(est)
         # algorithmic HBM bytes: both operands once, the output once (read-modify-write when accumulating), every
         # epilogue operand once
         nbytes = 2.0 * (m * k + n * k) + m * n * out.element_size() * (2 if accumulate else 1)
@@ -438,6 +458,14 @@ def cast_f32(src, dst):
     if src.numel() != dst.numel():
         raise RuntimeError("cast: size mismatch")
     L.check(L.load().ilvlm_cast_f32(src.data_ptr(), dst.data_ptr(), dt(dst), src.numel(), _stream()), "cast_f32")
+
+
+def cast_to_f32(src, dst):
+    """dst (fp32) = src (bf16)"""
+    _chk(src, "cast_to_f32.src", torch.bfloat16); _chk(dst, "cast_to_f32.dst", torch.float32)
+    if src.numel() != dst.numel():
+        raise RuntimeError("cast_to_f32: size mismatch")
+    L.check(L.load().ilvlm_cast_to_f32(src.data_ptr(), dt(src), dst.data_ptr(), src.numel(), _stream()), "cast_to_f32")
 
 
 def scale(x, y, a):

@@ -2,9 +2,11 @@
 
 One process per GPU, torchrun env contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), backend
 'nccl' (= RCCL over xGMI on MI355X).  convert_to_ddp_model returns a wrapper exposing `.module` like torch DDP, but
-gradient averaging is done on the flat gradient arena: the text-tower range is all-reduced on a side stream while the
-vision tower is still in backward, the rest when backward ends; unused and frozen parameters ride along as zeros
-(the reference needs find_unused_parameters=True for them)."""
+gradient averaging is done on the flat gradient arena: each transformer block's range is reduced on a side stream as
+soon as that block's backward is complete (the two towers announce their blocks from their own streams), the rest of
+the text side when the text backward ends and whatever is left at the end; unused and frozen parameters ride along as
+zeros (the reference needs find_unused_parameters=True for them).  In bf16 mode the buckets travel in bf16
+(comm.GradReducer; ILVLM_GRAD_BUCKET=fp32 restores fp32 buckets), fp32 mode reduces fp32 as the reference does."""
 import os
 import random
 
@@ -62,9 +64,10 @@ class NativeDDP(nn.Module):
         self.module = module
         module._eng.prepare()                      # adopt the parameters into the arena now
         arena = module._eng.arena
-        if comm.world()[1] > 1:
+        if comm._active(comm.world()[1]):
             distributed.broadcast(arena.P, 0)      # ONE flattened broadcast (reference: one per state_dict tensor)
-        arena.reducer = comm.GradReducer(arena.G)
+        bucket = os.environ.get("ILVLM_GRAD_BUCKET", "bf16" if module._eng.precision == "bf16" else "fp32")
+        arena.reducer = comm.GradReducer(arena.G, bucket=bucket)
         self._done = []                            # ranges already reduced in this backward
         object.__setattr__(module, "_grad_sync", self._on_sync)
 
@@ -104,6 +107,7 @@ class NativeDDP(nn.Module):
         return out
 
     def forward(self, *args, **kwargs):
+        self._done = []        # a backward that raised half-way must not leave ranges marked as reduced for the next step
         return self.module(*args, **kwargs)
 
 

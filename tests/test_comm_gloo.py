@@ -48,6 +48,17 @@ def _worker_primitives(rank, world, port, ret):
     want = torch.arange(10, dtype=torch.float32) * (rank + 1)
     want[2:7] = torch.arange(10, dtype=torch.float32)[2:7] * tot / world
     ok &= torch.allclose(flat, want)
+    # bf16 buckets (half the bytes on the wire): mean of the bf16-rounded values, widened back; untouched outside the range
+    vals = (torch.arange(200, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
+    flat = vals.clone()
+    red = comm.GradReducer(flat, bucket="bf16")
+    red.reduce_range(64, 192, chunk_elems=64)
+    red.wait()
+    per_rank = [((torch.arange(200, dtype=torch.float32) * 0.37 + 1.0) * (r + 1)).bfloat16() for r in range(world)]
+    mean = (sum(t.float() for t in per_rank) / world)          # gloo: SUM in bf16 then / W -- allow one more rounding
+    ok &= torch.equal(flat[:64], vals[:64]) and torch.equal(flat[192:], vals[192:])
+    ok &= bool(((flat[64:192] - mean[64:192]).abs() <= 2 ** -7 * mean[64:192].abs()).all())
+    ok &= red.bytes_sent == 128 * 2
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
