@@ -74,6 +74,15 @@ typedef struct ilvlm_gemm_epilogue {
     int out_group, out_skip;
     float* a_rowsum;        /* optional [M]: += sum_k A(m,k) (bias gradient fused into the weight-gradient GEMM:
                                A = dY^T); needs accumulate = 1, bf16 compute, K % 64 == 0, M % 8 == 0 */
+    /* token max-pool epilogue (FDT codebook scores, clip_fdt.py:113-145): when pool_out != NULL nothing is stored to C;
+     * instead pool_out[seq(m) * N + n] = max over the rows m of one sequence of (sortable key of alpha * acc) << 32 |
+     * (0x7fffffff - token index) by 64-bit atomic max, so the [M, N] score matrix never reaches memory.  seq(m) =
+     * pool_seq[m] and token = m - pool_offs[seq] (packed text rows), or m / pool_group and m % pool_group.  bf16 compute,
+     * direct-to-LDS kernels only; used through ilvlm_fdt_score_pool_fwd. */
+    unsigned long long* pool_out;
+    const int32_t* pool_seq;
+    const int32_t* pool_offs;
+    int pool_group;
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
@@ -135,6 +144,16 @@ int ilvlm_scatter_rows(const float* dy, const int64_t* idx, float* dx, int B, in
 int ilvlm_fdt_pool_fwd(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T, int C,
                        float sqrt_d, float temperature, int pool, void* stream);
 /* dscores[b,t,c] (dtype T) = dpooled[b,c] * d v / d s, routed to the argmax token for max pooling */
+/* Fused codebook scores + scale + token max-pool with argmax (clip_fdt.py:113-145 with pool_type 'max'):
+ * pooled[b,c] = max_t ((q[row(b,t)] . sd[c]) / sqrt_d) / temperature over the tokens of sequence b, argmax[b,c] = that t.
+ * The [rows, C] score matrix is never materialised: the bf16 MFMA GEMM's epilogue reduces each 32-row group per sequence
+ * and merges by 64-bit atomic max into `packed_ws` ([B, C] uint64, caller-owned scratch), which a decode pass turns into
+ * pooled / argmax.  Dense layout (seq_offs == NULL): rows = B * T, no pad mask (image side).  Packed text rows: seq_offs
+ * [B+1] and row_seq [rows] (sequence of every row); captions shorter than T also pool over their masked positions, which
+ * contribute exactly 0 (argmax = length marks "no token").  Requires temperature > 0, q / sd bf16, d % 64 == 0. */
+int ilvlm_fdt_score_pool_fwd(const void* q, const void* sd, unsigned long long* packed_ws, float* pooled, int* argmax,
+                             long rows, int B, int T, int C, int d, float sqrt_d, float temperature,
+                             const int32_t* seq_offs, const int32_t* row_seq, void* stream);
 int ilvlm_fdt_pool_bwd(const float* dpooled, const int* argmax, const float* pad_mask, void* dscores, int dtype,
                        int B, int T, int C, float sqrt_d, float temperature, int pool, void* stream);
 

@@ -402,7 +402,7 @@ struct DmaOperand {
 // code against a 64 KB instruction cache, and a workgroup that owns its CU stalled on instruction fetch for ~27 us per
 // tile (K-scaling, benchmarks/p8_scaling.py).  The variant is therefore a template parameter picked by one switch, and
 // the row-group loop is a real loop: the executed path of a tile is a few KB.
-enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, EPI_GELU_BWD };
+enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, EPI_GELU_BWD, EPI_POOLMAX };
 
 // one pass (32 rows: row tiles 2P, 2P+1) of epilogue_tile; the pass index is a template parameter so that the accumulator
 // array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
@@ -425,7 +425,32 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
         // LDS queue itself is in order.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if constexpr (MODE == EPI_GENERIC) {
+        if constexpr (MODE == EPI_POOLMAX) {
+            // token max-pool of the codebook scores: lane = column; the 32 rows are walked in order, a running (value, token)
+            // maximum per sequence is merged into pool_out by one 64-bit atomic max per sequence and column
+            const int col = n - 4 * c + lane;
+            int cur = -1;
+            unsigned long long best = 0;
+#pragma unroll 1
+            for (int r = 0; r < 32; ++r) {
+                const int m = m_base + P * 32 + r;
+                if (m >= ep.M) break;                                  // wave-uniform
+                const float v = alpha * *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
+                int sq, tok;
+                if (e.pool_seq) { sq = e.pool_seq[m]; tok = m - e.pool_offs[sq]; }
+                else { sq = m / e.pool_group; tok = m - sq * e.pool_group; }
+                if (sq != cur) {
+                    if (cur >= 0 && col < ep.N) atomicMax(e.pool_out + (long)cur * ep.N + col, best);
+                    cur = sq;
+                    best = 0;
+                }
+                const unsigned u = __float_as_uint(v);
+                const unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // order-preserving float -> uint
+                const unsigned long long cand = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - tok);
+                best = cand > best ? cand : best;
+            }
+            if (cur >= 0 && col < ep.N) atomicMax(e.pool_out + (long)cur * ep.N + col, best);
+        } else if constexpr (MODE == EPI_GENERIC) {
             // ragged tile, unaligned operands or a rare epilogue (row-indexed bias): one bounds-checked call per 4-row group
 #pragma unroll 1
             for (int hk = 0; hk < 8; ++hk) {
@@ -479,12 +504,13 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
     static_assert(TJ == 4 && (TI % 2) == 0, "64-column wave tiles, row tiles in pairs");
     const bool whole = ep.vec_ok && !e.accumulate && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
     int mode = EPI_GENERIC;
-    if (whole && !e.rowbias) {
+    if (e.pool_out) mode = EPI_POOLMAX;
+    else if (whole && !e.rowbias) {
         if (e.act == ILVLM_ACT_NONE) mode = e.residual ? EPI_RES : EPI_PLAIN;
         else if (!e.residual) mode = EPI_QGELU + (e.act - ILVLM_ACT_QUICKGELU);
     }
     const int n = n_base + 4 * (lane & 15);          // this lane's columns after the transpose
-    const f32x4 bias = (mode != EPI_GENERIC && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
+    const f32x4 bias = (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
     switch (mode) {
         case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
         case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
@@ -492,9 +518,46 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
         case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
         case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
         case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
         default: epilogue_pass<EPI_GENERIC, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
     }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// accumulate (split-K) epilogue: fragments (C^T orientation: lane owns row (l & 15), 4 consecutive columns) are
+// transposed through a wave-private 8 KiB LDS image so that every atomic wave-instruction covers 256 contiguous bytes
+// of one output row (the shape global float atomics run at full rate with)
+template <int TI, int TJ, int P = 0>
+__device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
+                                                  float alpha, unsigned char* wlds) {
+    static_assert(TJ == 4 && TI % 2 == 0, "64-column wave tile");
+    if constexpr (P < TI / 2) {
+        const int g = lane >> 4, c = lane & 15;
+        const int n = n_base + lane;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int row = ii * 16 + c;
+                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * P + ii][j];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (m_base + P * 32 < ep.M) {
+#pragma unroll 4
+            for (int r = 0; r < 32; ++r) {
+                const int m = m_base + P * 32 + r;
+                const float v = *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
+                if (m < ep.M && n < ep.N)
+                    atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, v * alpha);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_acc_tile<TI, TJ, P + 1>(ep, acc, m_base, n_base, lane, alpha, wlds);
+    }
+}
+#endif
 
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
@@ -611,13 +674,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
-            if (rowsum) {
+                for (int j = 0; j < TJ; ++j)      // C^T fragments: lane owns row (l & 15), 4 consecutive columns
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (rowsum) {                         // every register of lane c = row sum of operand row c
 #pragma unroll
-                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accb[i], 0, 0, 0);
             }
         }
 #ifdef ILVLM_GEMM_STAMPS
@@ -651,32 +712,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #if ILVLM_GEMM_ABLATE == 3
     if (acc[0][0][0] != 12345.678f) return;
 #endif
+    // every wave must be done reading the operand tiles before any wave overwrites them with its fragments
+    __syncthreads();
     if (SWAP) {
-        // every wave must be done reading the operand tiles before any wave overwrites them with its fragments
-        __syncthreads();
         epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
     } else {
-        const int g = lane >> 4, c = lane & 15;
+        // split-K accumulate: atomics in whole 256-byte row segments (see epilogue_acc_tile)
+        epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+        if (rowsum && lane < 16) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int n = nw + j * 16 + c;
-                if (n < ep.N) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mw + i * 16 + 4 * g + r;
-                        if (m < ep.M)
-                            atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, acc[i][j][r] * alpha);
-                    }
-                }
-            }
-            if (rowsum && c == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mw + i * 16 + 4 * g + r;
-                    if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][r]);
-                }
+            for (int i = 0; i < TI; ++i) {
+                const int m = mw + i * 16 + lane;
+                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][0]);
             }
         }
     }
@@ -843,39 +890,6 @@ struct P8Tile {
     }
 };
 
-// accumulate epilogue of the phased kernel: fragments (C^T orientation: lane owns row (l & 15), 4 consecutive columns) are
-// transposed through a wave-private 8 KiB LDS image so that every atomic wave-instruction covers 256 contiguous bytes
-// of one output row (the shape global float atomics run at full rate with)
-template <int TI, int TJ, int P = 0>
-__device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
-                                                  float alpha, unsigned char* wlds) {
-    static_assert(TJ == 4 && TI % 2 == 0, "64-column wave tile");
-    if constexpr (P < TI / 2) {
-        const int g = lane >> 4, c = lane & 15;
-        const int n = n_base + lane;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int row = ii * 16 + c;
-                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * P + ii][j];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (m_base + P * 32 < ep.M) {
-#pragma unroll 4
-            for (int r = 0; r < 32; ++r) {
-                const int m = m_base + P * 32 + r;
-                const float v = *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
-                if (m < ep.M && n < ep.N)
-                    atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, v * alpha);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        epilogue_acc_tile<TI, TJ, P + 1>(ep, acc, m_base, n_base, lane, alpha, wlds);
-    }
-}
 #endif
 
 template <bool TA, bool TB, bool ACC>
@@ -1075,7 +1089,7 @@ template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NST
 int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
     auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT>;
     // operand ring; the SWAP epilogue transposes through 8 KiB per wave of the same allocation
-    constexpr int ring = NSTAGE * (DBM + DBN) * BKT * 2, epi = SWAP ? WM * WN * 8192 : 0;
+    constexpr int ring = NSTAGE * (DBM + DBN) * BKT * 2, epi = WM * WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -1139,6 +1153,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ILVLM_REQUIRE(epi->act >= 0 && epi->act <= ILVLM_ACT_GELU_ERF_BWD, "gemm: bad act %d", epi->act);
     ILVLM_REQUIRE(!(epi->a_rowsum && !(epi->accumulate && compute_dtype == ILVLM_BF16)),
                   "gemm: a_rowsum needs accumulate and bf16 compute");
+    ILVLM_REQUIRE(!epi->pool_out || (compute_dtype == ILVLM_BF16 && !epi->accumulate && !epi->bias && !epi->rowbias &&
+                                     !epi->residual && !epi->act && epi->out_group == 0 &&
+                                     ((epi->pool_seq && epi->pool_offs) || epi->pool_group > 0)),
+                  "gemm: the pool epilogue needs bf16 compute, no other epilogue term, and pool_seq + pool_offs or pool_group");
     hipStream_t s = (hipStream_t)stream;
     EpiArgs ep;
     ep.e = *epi;
@@ -1165,7 +1183,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // K-contiguous operands need whole K-tiles (a partial one would run into the next row); when both operands are
         // K-strided (weight gradients: the contraction runs over token rows) the k-rows past K lie beyond the buffer
         // descriptors' extent and read as zeros, so any K works -- the packed text rows need exactly that.
-        const bool fast = variant != 0 && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
+        const bool fast = (variant != 0 || epi->pool_out) && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
         // 8 = 256x256 phased kernel (one workgroup per CU): the tall GEMMs of the towers
         if (fast && variant == 8 && M >= 256 && N >= 256) {
@@ -1201,6 +1219,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 #undef ILVLM_DMA
         }
         ILVLM_REQUIRE(epi->a_rowsum == nullptr, "gemm: a_rowsum needs the direct-to-LDS path (K %% 64 == 0, M %% 8 == 0)");
+        ILVLM_REQUIRE(epi->pool_out == nullptr, "gemm: the pool epilogue needs the direct-to-LDS path (K %% 64 == 0)");
 #define ILVLM_DISPATCH(TA, TB)                                                                       \
     return swap ? launch_bf16<TA, TB, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)               \
                 : launch_bf16<TA, TB, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)

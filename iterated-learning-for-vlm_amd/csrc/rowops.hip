@@ -477,6 +477,57 @@ extern "C" int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, co
     return ILVLM_OK;
 }
 
+// ---- fused scores + max-pool: initial value and decode of the packed (key << 32 | 0x7fffffff - token) words
+__global__ __launch_bounds__(256) void fdt_pack_init_kernel(unsigned long long* __restrict__ w, int C, int T,
+                                                            const int* __restrict__ seq_offs) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    unsigned long long v = 0;                   // below the key of every float, -inf included
+    if (seq_offs) {
+        const int len = seq_offs[b + 1] - seq_offs[b];
+        // masked positions of a short caption contribute exactly 0; token index = len marks "no token"
+        if (len < T) v = ((unsigned long long)0x80000000u << 32) | (unsigned)(0x7fffffff - len);
+    }
+    w[(long)b * C + c] = v;
+}
+__global__ __launch_bounds__(256) void fdt_pack_decode_kernel(const unsigned long long* __restrict__ w, float* __restrict__ pooled,
+                                                              int* __restrict__ argmax, long n, float sqrt_d, float temp) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = w[i];
+    const unsigned key = (unsigned)(v >> 32);
+    const unsigned u = (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key;
+    pooled[i] = (__uint_as_float(u) / sqrt_d) / temp;      // the same two roundings as fdt_pool_fwd_kernel applies per token
+    argmax[i] = 0x7fffffff - (int)(unsigned)(v & 0xffffffffu);
+}
+
+extern "C" int ilvlm_fdt_score_pool_fwd(const void* q, const void* sd, unsigned long long* packed_ws, float* pooled,
+                                        int* argmax, long rows, int B, int T, int C, int d, float sqrt_d, float temperature,
+                                        const int32_t* seq_offs, const int32_t* row_seq, void* stream) {
+    ILVLM_REQUIRE(q && sd && packed_ws && pooled && argmax, "fdt_score_pool_fwd: null pointer");
+    ILVLM_REQUIRE(rows > 0 && B > 0 && T > 0 && C > 0 && d > 0 && d % 64 == 0, "fdt_score_pool_fwd: bad shape (d %% 64 == 0)");
+    ILVLM_REQUIRE(sqrt_d > 0.f && temperature > 0.f, "fdt_score_pool_fwd: needs sqrt_d > 0 and temperature > 0");
+    ILVLM_REQUIRE((seq_offs != nullptr) == (row_seq != nullptr), "fdt_score_pool_fwd: seq_offs and row_seq go together");
+    ILVLM_REQUIRE(seq_offs || rows == (long)B * T, "fdt_score_pool_fwd: dense layout needs rows == B * T");
+    hipLaunchKernelGGL(fdt_pack_init_kernel, dim3(ceil_div(C, 256), B), dim3(256), 0, S_, packed_ws, C, T, seq_offs);
+    ILVLM_LAUNCH_CHECK("fdt_score_pool_fwd(init)");
+    ilvlm_gemm_epilogue ep = {};
+    ep.alpha = 1.0f;
+    ep.out_dtype = ILVLM_F32;
+    ep.pool_out = packed_ws;
+    ep.pool_seq = row_seq;
+    ep.pool_offs = seq_offs;
+    ep.pool_group = T;
+    // C is never written by the pool epilogue; the scratch pointer only satisfies the argument checks
+    int rc = ilvlm_gemm(ILVLM_BF16, 0, 0, (int)rows, C, d, q, d, sd, d, packed_ws, C, &ep, 1, stream);
+    if (rc) return rc;
+    const long n = (long)B * C;
+    hipLaunchKernelGGL(fdt_pack_decode_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, S_, packed_ws, pooled, argmax, n, sqrt_d,
+                       temperature);
+    ILVLM_LAUNCH_CHECK("fdt_score_pool_fwd(decode)");
+    return ILVLM_OK;
+}
+
 static int fdt_pool_fwd_impl(const float* scores, const float* pad_mask, float* pooled, int* argmax, int B, int T, int C,
                              float sqrt_d, float temperature, int pool, const int* seq_offs, void* stream) {
     ILVLM_REQUIRE(scores && pooled && B > 0 && T > 0 && C > 0, "fdt_pool_fwd: bad args");

@@ -122,6 +122,7 @@ class Engine:
         self._wg = {}
         self._wg_keep = {}      # tower stream -> tensors its companion stream still reads
         self.composite = os.environ.get("ILVLM_COMPOSITE", "1") == "1"    # one C call per transformer block
+        self.fused_fdt = os.environ.get("ILVLM_FUSED_FDT", "1") == "1"    # codebook scores + token max-pool in one GEMM
         self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
     @property
@@ -518,13 +519,19 @@ class Engine:
         cfg, Wf = self.cfg, self.Wf
         sd = Wf["space_dict"]
         Cn, d = sd.shape
-        scores = _empty((q.shape[0], Cn), torch.float32, q)
-        ops.gemm(q, self._mat("space_dict"), scores)
         pooled = _empty((B, Cn), torch.float32, q)
         pool = POOLS[cfg["pool"]]
         argmax = _empty((B, Cn), torch.int32, q) if pool == POOL_MAX else None
-        ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool, seq)
-        del scores
+        fused = (self.fused_fdt and pool == POOL_MAX and self.T == torch.bfloat16 and d % 64 == 0 and float(temperature) > 0
+                 and (mask is None or seq is not None))
+        if fused:
+            # scores, scale and the token max + argmax in the GEMM epilogue: the [rows, 4096] fp32 scores never reach HBM
+            ops.fdt_score_pool_fwd(q, self._mat("space_dict"), pooled, argmax, B, Tn, math.sqrt(d), float(temperature), seq)
+        else:
+            scores = _empty((q.shape[0], Cn), torch.float32, q)
+            ops.gemm(q, self._mat("space_dict"), scores)
+            ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool, seq)
+            del scores
         att_w = torch.empty_like(pooled)
         if cfg["att_func"] == "sparsemax":
             ops.sparsemax_fwd(pooled, att_w)

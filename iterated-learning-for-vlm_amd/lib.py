@@ -16,7 +16,8 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("rowbias", vp), ("residual", vp), ("aux", vp), ("alpha_ptr", vp),
                 ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
-                ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp)]
+                ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp),
+                ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32)]
 
 
 class Block(C.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "ilvlm_scatter_rows": [vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_fdt_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp],
     "ilvlm_fdt_pool_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],
+    "ilvlm_fdt_score_pool_fwd": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp, vp, vp],
     "ilvlm_sparsemax_fwd": [vp, vp, i32, i32, vp],
     "ilvlm_sparsemax_bwd": [vp, vp, vp, i32, i32, vp],
     "ilvlm_softmax_fwd": [vp, vp, i32, i32, vp],

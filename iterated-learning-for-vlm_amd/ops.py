@@ -260,6 +260,16 @@ class PackedSeq(object):
         self.B, self.ctx, self.rows, self.cap = len(lens), int(ctx), offs[-1], max(lens)
         self.lengths = lens
         self.offs = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+        self._row_seq = None
+        self._device = device
+
+    @property
+    def row_seq(self):
+        """int32 [rows]: the sequence every packed row belongs to (host metadata like `offs`; built on first use)"""
+        if self._row_seq is None:
+            lens = torch.tensor(self.lengths, dtype=torch.int64)
+            self._row_seq = torch.repeat_interleave(torch.arange(self.B, dtype=torch.int32), lens).to(self._device, non_blocking=True)
+        return self._row_seq
 
 
 def attention_fwd(qkv, out, lse, B, Lq, H, causal, seq=None):
@@ -370,6 +380,21 @@ def fdt_pool_fwd(scores, mask, pooled, argmax, B, T, Cn, sqrt_d, temp, pool, seq
         return
     L.check(L.load().ilvlm_fdt_pool_fwd(scores.data_ptr(), _p(mask), pooled.data_ptr(), _p(argmax), B, T, Cn, sqrt_d,
                                         temp, pool, _stream()), "fdt_pool_fwd")
+
+
+def fdt_score_pool_fwd(q, sd, pooled, argmax, B, T, sqrt_d, temp, seq=None):
+    """fused codebook scores + scale + token max-pool (ilvlm_fdt_score_pool_fwd): q [rows,d] bf16, sd [C,d] bf16"""
+    rows, d = q.shape
+    Cn = sd.shape[0]
+    _chk(q, "fdt.q", torch.bfloat16); _chk(sd, "fdt.sd", torch.bfloat16, (Cn, d))
+    _chk(pooled, "fdt.pooled", torch.float32, (B, Cn)); _chk(argmax, "fdt.argmax", torch.int32, (B, Cn))
+    if rows != (seq.rows if seq is not None else B * T):
+        raise RuntimeError("fdt_score_pool_fwd: q has %d rows, layout says %d" % (rows, seq.rows if seq is not None else B * T))
+    ws = torch.empty((B, Cn), dtype=torch.int64, device=q.device)
+    L.check(L.load().ilvlm_fdt_score_pool_fwd(q.data_ptr(), sd.data_ptr(), ws.data_ptr(), pooled.data_ptr(), argmax.data_ptr(),
+                                              rows, B, T, Cn, d, sqrt_d, temp, seq.offs.data_ptr() if seq is not None else None,
+                                              seq.row_seq.data_ptr() if seq is not None else None, _stream()),
+            "fdt_score_pool_fwd")
 
 
 def fdt_pool_bwd(dpooled, argmax, mask, dscores, B, T, Cn, sqrt_d, temp, pool, seq=None):

@@ -691,3 +691,37 @@ def test_attention_at_full_size_is_deterministic_and_right(B, L, H, causal, pack
         ops.attention_fwd(q1, o1, l1, 1, n, H, causal)
         ops.attention_bwd(dout[o:o + n].contiguous(), q1, o1, l1, d1, 1, n, H, causal)
         assert rel(first[0][o:o + n], o1.float().cpu()) < 1e-2 and rel(first[1][o:o + n], d1.float().cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("B,T,C,d,packed", [(5, 49, 320, 64, False), (7, 24, 256, 128, True), (64, 49, 4096, 512, False),
+                                             (48, 77, 4096, 512, True)])
+def test_fused_fdt_score_pool_equals_scores_then_pool(B, T, C, d, packed):
+    """the GEMM epilogue that max-pools the codebook scores over the tokens of each sequence (no [rows, C] score matrix)
+    against the two-kernel form: same pooled values bit for bit (same MFMA sums, same two scalings), same argmax; packed
+    rows with captions shorter than the context (their masked positions contribute exactly 0, argmax = length)"""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(5)
+    lens = torch.randint(3, T + 1, (B,), generator=gen).tolist() if packed else [T] * B
+    if packed:
+        lens[0], lens[1] = T, 3
+    seq = ops.PackedSeq(lens, T, "cuda") if packed else None
+    rows = sum(lens)
+    q = (rnd(rows, d, seed=1) - (0.3 if packed else 0.0)).to(torch.bfloat16).cuda()
+    sd = rnd(C, d, seed=2).to(torch.bfloat16).cuda()
+    sqrt_d, temp = math.sqrt(d), 1000.0
+    scores = torch.empty(rows, C, device="cuda")
+    ops.gemm(q, sd, scores)
+    want_p = torch.empty(B, C, device="cuda"); want_a = torch.empty(B, C, device="cuda", dtype=torch.int32)
+    ops.fdt_pool_fwd(scores, None, want_p, want_a, B, T, C, sqrt_d, temp, 0, seq)
+    got_p = torch.full((B, C), float("nan"), device="cuda"); got_a = torch.full((B, C), -1, device="cuda", dtype=torch.int32)
+    ops.fdt_score_pool_fwd(q, sd, got_p, got_a, B, T, sqrt_d, temp, seq)
+    torch.cuda.synchronize()
+    assert torch.equal(got_p, want_p)
+    same = got_a == want_a
+    if not bool(same.all()):      # a tie between two tokens of a sequence (equal fp32 scores): either index is a maximum
+        offs = torch.tensor([0] + list(np.cumsum(lens)), device="cuda")
+        b_idx, c_idx = torch.nonzero(~same, as_tuple=True)
+        for b, c_ in zip(b_idx.tolist()[:50], c_idx.tolist()[:50]):
+            assert float(scores[offs[b] + got_a[b, c_], c_]) == float(scores[offs[b] + want_a[b, c_], c_])
+    if packed:
+        assert bool((got_a[1] <= 3).all()) and bool((got_p[1] >= 0).all())      # the 3-token caption: zeros can win
