@@ -182,6 +182,16 @@ int ilvlm_infonce_fwd(const float* logits_i, const float* logits_t, int B, int B
 /* accuracy() of misc.py:464-477: out[0] = 100/B * #{rows whose label is in the top-1}, out[1] same for top-k */
 int ilvlm_topk_accuracy(const float* logits, int B, int Bg, int label_offset, int k, float* out, void* stream);
 
+/* ---- input pipeline: uint8 image batch -> normalised fp32 NCHW on the device.
+ * dst[b,c,y,x] = (src(b,c,y,x') / 255 - mean[c]) / std[c], i.e. transforms.ToTensor + transforms.Normalize of
+ * prototype/data/imagenet_dataloader.py:13-14 (the tail of every augmentation list, :59-68), with the two MOCOV2_single
+ * augmentations that are pure pixel functions once their coin is tossed: flags[b] bit 0 = horizontal flip (x' = W-1-x),
+ * bit 1 = grayscale (PIL "L" luma, replicated to 3 channels).  src is [B,H,W,3] (nhwc = 1) or [B,3,H,W] uint8; flags may
+ * be NULL; mean3 / std3 are HOST arrays of 3 floats.  The multiplication by 1/std rounds once more than a division: results
+ * equal the float CPU pipeline to 1 ulp (tests/test_input_pipeline_gpu.py). */
+int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, const unsigned char* flags, float* dst, int B, int H, int W,
+                             const float* mean3, const float* std3, void* stream);
+
 /* ---- small utilities ---- */
 /* out[c] += sum_r x[r,c]  (bias gradients) */
 int ilvlm_colsum(const void* x, int dtype, float* out, long rows, int cols, int ld, void* stream);

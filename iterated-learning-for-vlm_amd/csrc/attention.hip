@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 VALU kernels (parity mode; L <= 96 forward, L <= 80 backward)
+// fp32 VALU kernels (parity mode; LDS-resident for L <= 96 forward / 80 backward, global-memory forms beyond)
 // ---------------------------------------------------------------------------------------------
 constexpr int LDF = HD + 1;
 
@@ -619,6 +619,106 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ do
     }
 }
 
+
+// fp32 kernels for sequences that do not fit the LDS-resident forms above (ViT-B/16: 197, ViT-L/14: 257 tokens; parity mode
+// only, so clarity over speed): one wave per query row (forward, dQ) or per key row (dK, dV); K / V / Q rows come straight
+// from global memory (L2-resident at these sizes), probabilities are recomputed from the saved log-sum-exp.
+constexpr int LMAX_F32 = 320;
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_long(const float* __restrict__ qkv, float* __restrict__ out,
+                                                         float* __restrict__ lse, int L, int H, int causal) {
+    __shared__ float qs[4][HD];
+    __shared__ float ps[4][LMAX_F32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H, q = blockIdx.y * 4 + wave;
+    if (q >= L) return;                                   // whole wave
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const float* base = qkv + (long)b * L * rs + h * HD;
+    qs[wave][lane] = base[(long)q * rs + lane] * 0.125f;
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY;
+    for (int k = lane; k < L; k += 64) {
+        float sc = 0.f;
+        const float* kr = base + E + (long)k * rs;
+        for (int d = 0; d < HD; ++d) sc = fmaf(qs[wave][d], kr[d], sc);
+        if (causal && k > q) sc = -INFINITY;
+        ps[wave][k] = sc;
+        m = fmaxf(m, sc);
+    }
+    m = wave_max(m);
+    float t = 0.f;
+    for (int k = lane; k < L; k += 64) t += __expf(ps[wave][k] - m);
+    t = wave_sum(t);
+    for (int k = lane; k < L; k += 64) ps[wave][k] = __expf(ps[wave][k] - m) / t;
+    if (lane == 0) lse[((long)b * H + h) * L + q] = m + __logf(t);
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int k = 0; k < L; ++k) o = fmaf(ps[wave][k], base[2 * E + (long)k * rs + lane], o);
+    out[((long)b * L + q) * E + h * HD + lane] = o;
+}
+
+// role 0 (blockIdx.z == 0): wave per query row -> dQ; role 1: wave per key row -> dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_f32_long(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                         const float* __restrict__ outp, const float* __restrict__ lse,
+                                                         float* __restrict__ dqkv, int L, int H, int causal) {
+    __shared__ float r0[4][HD], r1[4][HD];
+    __shared__ float w0[4][LMAX_F32], w1[4][LMAX_F32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H, row = blockIdx.y * 4 + wave;
+    if (row >= L) return;
+    const int E = HD * H;
+    const long rs = 3L * E;
+    const float* base = qkv + (long)b * L * rs + h * HD;
+    const float* dob = dout + (long)b * L * E + h * HD;
+    const float* ob = outp + (long)b * L * E + h * HD;
+    const float* ls = lse + ((long)b * H + h) * L;
+    float* o = dqkv + ((long)b * L + row) * rs + h * HD + lane;
+    if (blockIdx.z == 0) {
+        const int q = row;
+        r0[wave][lane] = base[(long)q * rs + lane] * 0.125f;            // scaled q
+        r1[wave][lane] = dob[(long)q * E + lane];                       // dO row
+        const float delta = wave_sum(dob[(long)q * E + lane] * ob[(long)q * E + lane]);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < L; k += 64) {
+            float sc = 0.f, dp = 0.f;
+            const float *kr = base + E + (long)k * rs, *vr = base + 2 * E + (long)k * rs;
+            for (int d = 0; d < HD; ++d) { sc = fmaf(r0[wave][d], kr[d], sc); dp = fmaf(r1[wave][d], vr[d], dp); }
+            const float p = (causal && k > q) ? 0.f : __expf(sc - ls[q]);
+            w0[wave][k] = p * (dp - delta);                             // dS[q][k]
+        }
+        __builtin_amdgcn_wave_barrier();
+        float dq = 0.f;
+        for (int k = 0; k < L; ++k) dq = fmaf(w0[wave][k], base[E + (long)k * rs + lane], dq);
+        o[0] = dq * 0.125f;
+    } else {
+        const int k = row;
+        r0[wave][lane] = base[E + (long)k * rs + lane];                 // K row
+        r1[wave][lane] = base[2 * E + (long)k * rs + lane];             // V row
+        __builtin_amdgcn_wave_barrier();
+        for (int q = lane; q < L; q += 64) {
+            float sc = 0.f, dp = 0.f, delta = 0.f;
+            const float *qr = base + (long)q * rs, *dr = dob + (long)q * E, *orow = ob + (long)q * E;
+            for (int d = 0; d < HD; ++d) {
+                sc = fmaf(qr[d] * 0.125f, r0[wave][d], sc);
+                dp = fmaf(dr[d], r1[wave][d], dp);
+                delta = fmaf(dr[d], orow[d], delta);
+            }
+            const float p = (causal && k > q) ? 0.f : __expf(sc - ls[q]);
+            w0[wave][q] = p;
+            w1[wave][q] = p * (dp - delta);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float dv = 0.f, dk = 0.f;
+        for (int q = 0; q < L; ++q) {
+            dv = fmaf(w0[wave][q], dob[(long)q * E + lane], dv);
+            dk = fmaf(w1[wave][q], base[(long)q * rs + lane] * 0.125f, dk);
+        }
+        o[E] = dk;
+        o[2 * E] = dv;
+    }
+}
+
 template <class K>
 int set_lds(K kern, int bytes, const char* name) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -710,7 +810,13 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype,
         ILVLM_FAIL(ILVLM_ERR_ARG, "attention_fwd(bf16): no kernel for L=%d", L);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_fwd: bad dtype %d", dtype);
-    ILVLM_REQUIRE(L <= 96, "attention_fwd(f32): L=%d > 96 not supported", L);
+    if (Lcap > 96) {            // long sequences (ViT-B/16, ViT-L/14 in fp32 parity mode): global-memory kernel
+        ILVLM_REQUIRE(!seq_offs && L <= LMAX_F32, "attention_fwd(f32): L=%d > %d (or packed rows > 96) not supported", L, LMAX_F32);
+        hipLaunchKernelGGL(attn_fwd_f32_long, dim3(B * H, ceil_div(L, 4)), dim3(256), 0, s, (const float*)qkv, (float*)out, lse, L,
+                           H, causal);
+        ILVLM_LAUNCH_CHECK("attention_fwd_f32_long");
+        return ILVLM_OK;
+    }
     int bytes = (3 * Lcap * LDF + Lcap * (Lcap + 1)) * 4;
     static bool done_f = false;
     if (!done_f) {
@@ -760,7 +866,13 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
         return launch_bwd_tiled_bf16<288>(d, q, o, lse, dq, B, L, H, causal, s);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_bwd: bad dtype %d", dtype);
-    ILVLM_REQUIRE(L <= 80, "attention_bwd(f32): L=%d > 80 not supported", L);
+    if (Lcap > 80) {
+        ILVLM_REQUIRE(!seq_offs && L <= LMAX_F32, "attention_bwd(f32): L=%d > %d (or packed rows > 80) not supported", L, LMAX_F32);
+        hipLaunchKernelGGL(attn_bwd_f32_long, dim3(B * H, ceil_div(L, 4), 2), dim3(256), 0, s, (const float*)dout,
+                           (const float*)qkv, (const float*)out, lse, (float*)dqkv, L, H, causal);
+        ILVLM_LAUNCH_CHECK("attention_bwd_f32_long");
+        return ILVLM_OK;
+    }
     int bytes = (4 * Lcap * LDF + 2 * Lcap * (Lcap + 1) + Lcap) * 4;
     static bool done_b = false;
     if (!done_b) {

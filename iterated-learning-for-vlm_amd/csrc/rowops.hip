@@ -477,6 +477,47 @@ extern "C" int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, co
     return ILVLM_OK;
 }
 
+// ---- input pipeline: uint8 image batch (as decoded / cropped by the loader's workers) -> normalised fp32 NCHW on the device.
+// ToTensor (/255) + Normalize(mean, std) of prototype/data/imagenet_dataloader.py:13-14,59-68 and the two augmentations of
+// MOCOV2_single whose effect is a pure function of the pixels once their coin is tossed: RandomHorizontalFlip (flag bit 0)
+// and RandomGrayscale (flag bit 1; PIL's ITU-R 601-2 luma (19595 R + 38470 G + 7471 B + 32768) >> 16, replicated).
+struct ImgNorm { float mean[3], inv_std[3]; };
+__global__ __launch_bounds__(256) void image_u8_kernel(const unsigned char* __restrict__ src, const unsigned char* __restrict__ flags,
+                                                       float* __restrict__ dst, int H, int W, int nhwc, ImgNorm nm) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int f = flags ? flags[b] : 0;
+    const int xs = (f & 1) ? W - 1 - x : x;
+    const long plane = (long)H * W;
+    int px[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        px[ch] = nhwc ? src[(((long)b * H + y) * W + xs) * 3 + ch] : src[((long)b * 3 + ch) * plane + (long)y * W + xs];
+    if (f & 2) {
+        const int l = (px[0] * 19595 + px[1] * 38470 + px[2] * 7471 + 0x8000) >> 16;
+        px[0] = px[1] = px[2] = l;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        dst[((long)b * 3 + ch) * plane + (long)y * W + x] = ((float)px[ch] / 255.0f - nm.mean[ch]) * nm.inv_std[ch];
+}
+
+extern "C" int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, const unsigned char* flags, float* dst, int B, int H,
+                                        int W, const float* mean3, const float* std3, void* stream) {
+    ILVLM_REQUIRE(src && dst && mean3 && std3 && B > 0 && H > 0 && W > 0, "image_u8_normalize: bad args");
+    ILVLM_REQUIRE(B <= 65535 && H <= 65535, "image_u8_normalize: batch / height too large for one launch");
+    ImgNorm nm;
+    for (int i = 0; i < 3; ++i) {
+        ILVLM_REQUIRE(std3[i] > 0.f, "image_u8_normalize: std must be positive");
+        nm.mean[i] = mean3[i];
+        nm.inv_std[i] = 1.0f / std3[i];
+    }
+    hipLaunchKernelGGL(image_u8_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, S_, src, flags, dst, H, W, nhwc ? 1 : 0, nm);
+    ILVLM_LAUNCH_CHECK("image_u8_normalize");
+    return ILVLM_OK;
+}
+
 // ---- fused scores + max-pool: initial value and decode of the packed (key << 32 | 0x7fffffff - token) words
 __global__ __launch_bounds__(256) void fdt_pack_init_kernel(unsigned long long* __restrict__ w, int C, int T,
                                                             const int* __restrict__ seq_offs) {

@@ -50,6 +50,8 @@ class ParamArena:
         self.S = torch.zeros(off, device=dev, dtype=torch.bfloat16) if precision == "bf16" else None
         self.views, self.gviews, self.sviews = {}, {}, {}
         self.inactive = set()     # parameters the loss never reaches (no gradient, untouched by the optimizer)
+        self.shadow_fresh = False # set by the fused optimizer: its kernel wrote the bf16 shadow of what it updated
+        self._versions = None
         self.reducer = None       # comm.GradReducer installed by the data-parallel wrapper
         for n, p in self.named:
             o, k = self.offsets[n], p.numel()
@@ -65,16 +67,25 @@ class ParamArena:
 
     def sync_in(self):
         """Re-adopt parameters whose storage was replaced behind our back (p.data = ..., load_state_dict on a
-        moved module) and re-attach gradient views dropped by zero_grad(set_to_none=True)."""
+        moved module) and re-attach gradient views dropped by zero_grad(set_to_none=True).  Returns True when a
+        parameter's storage had been replaced."""
+        swapped = False
         for n, p in self.named:
             v = self.views[n]
             if p.data_ptr() != v.data_ptr():
                 v.copy_(p.data.to(v.device, torch.float32))
                 p.data = v
+                swapped = True
             if p.grad is None or p.grad.data_ptr() != self.gviews[n].data_ptr():
                 if p.grad is not None:
                     self.gviews[n].copy_(p.grad)
                 p.grad = self.gviews[n]
+        return swapped
+
+    def versions(self):
+        """autograd version counters of the parameters: every in-place write through the Parameter (load_state_dict,
+        reset_parameters, p.copy_, p.clamp_ under no_grad) bumps one"""
+        return tuple(p._version for _, p in self.named)
 
     def refresh_shadow(self):
         if self.S is not None:
@@ -123,6 +134,7 @@ class Engine:
         self._wg_keep = {}      # tower stream -> tensors its companion stream still reads
         self.composite = os.environ.get("ILVLM_COMPOSITE", "1") == "1"    # one C call per transformer block
         self.fused_fdt = os.environ.get("ILVLM_FUSED_FDT", "1") == "1"    # codebook scores + token max-pool in one GEMM
+        self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
         self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
     @property
@@ -141,10 +153,20 @@ class Engine:
         if self.arena is None:
             self.arena = ParamArena(self.m, self.precision)
             self.arena.inactive = set(self.m.unused_parameter_names())
+            swapped = True
         else:
-            self.arena.sync_in()
-        self.arena.refresh_shadow()
+            swapped = self.arena.sync_in()
         a = self.arena
+        # The bf16 shadow is re-cast from the fp32 masters (0.2 ms for 155 M parameters) unless it is provably current:
+        # the fused AdamW wrote the shadow of everything it updated, no parameter storage was replaced and no Parameter
+        # was written in place since (version counters).  A write through `p.data` is invisible to both checks -- the
+        # reference solver only does that to logit_scale, which the kernels read in fp32 -- so code that edits GEMM weights
+        # that way calls mark_dirty() (or sets ILVLM_TRUST_SHADOW=0).
+        vers = a.versions()
+        if not (self.trust_shadow and a.shadow_fresh and not swapped and vers == a._versions):
+            a.refresh_shadow()
+        a.shadow_fresh = False
+        a._versions = vers
         self.Wf = a.views                                     # fp32 masters
         self.Wc = a.sviews if self.precision == "bf16" else a.views   # GEMM operands
         self.Gr = a.gviews
@@ -152,6 +174,12 @@ class Engine:
         if req != getattr(self, "req", None):
             self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots
         self.req = req
+
+    def mark_dirty(self):
+        """the fp32 masters were edited behind the engine's back (through p.data): re-cast the bf16 shadow next forward"""
+        if self.arena is not None:
+            self.arena.shadow_fresh = False
+            self.arena._versions = None
 
     def _wgrad_stream(self):
         """companion stream of the current stream for weight-gradient GEMMs (ILVLM_WGRAD_STREAMS=0 switches it off)"""

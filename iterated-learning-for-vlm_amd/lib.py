@@ -62,6 +62,7 @@ SIGNATURES = {
     "ilvlm_infonce_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "ilvlm_topk_accuracy": [vp, i32, i32, i32, i32, vp, vp],
     "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
+    "ilvlm_image_u8_normalize": [vp, i32, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
     "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
     "ilvlm_cast_to_f32": [vp, i32, vp, i64, vp],
     "ilvlm_scale": [vp, vp, f32, i64, vp],

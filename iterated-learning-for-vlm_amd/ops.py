@@ -485,6 +485,31 @@ def cast_f32(src, dst):
     L.check(L.load().ilvlm_cast_f32(src.data_ptr(), dst.data_ptr(), dt(dst), src.numel(), _stream()), "cast_f32")
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # imagenet_dataloader.py:13-14
+
+
+def image_u8_normalize(src, dst=None, flags=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 image batch [B,H,W,3] or [B,3,H,W] (device) -> fp32 [B,3,H,W], ToTensor + Normalize, optional per-sample
+    flags (uint8 [B]: bit 0 horizontal flip, bit 1 grayscale)."""
+    _chk(src, "image.src", torch.uint8)
+    if src.dim() != 4 or (src.shape[3] != 3 and src.shape[1] != 3):
+        raise RuntimeError("image_u8_normalize: expected [B,H,W,3] or [B,3,H,W] uint8, got %s" % (tuple(src.shape),))
+    if src.shape[3] == 3 and src.shape[1] == 3:
+        raise RuntimeError("image_u8_normalize: ambiguous layout (3 rows or 3 columns); pass a real image size")
+    nhwc = src.shape[3] == 3
+    B = src.shape[0]
+    H, W = (src.shape[1], src.shape[2]) if nhwc else (src.shape[2], src.shape[3])
+    if dst is None:
+        dst = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    _chk(dst, "image.dst", torch.float32, (B, 3, H, W))
+    if flags is not None:
+        _chk(flags, "image.flags", torch.uint8, (B,))
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(L.load().ilvlm_image_u8_normalize(src.data_ptr(), int(nhwc), _p(flags), dst.data_ptr(), B, H, W, m3, s3, _stream()),
+            "image_u8_normalize")
+    return dst
+
+
 def cast_to_f32(src, dst):
     """dst (fp32) = src (bf16)"""
     _chk(src, "cast_to_f32.src", torch.bfloat16); _chk(dst, "cast_to_f32.dst", torch.float32)

@@ -116,6 +116,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                           arena.S.data_ptr() if arena.S is not None else None, self._coff.data_ptr(),
                                           self._ccnt.data_ptr(), self._cgrp.data_ptr(), int(self._coff.numel()), C.byref(h),
                                           torch.cuda.current_stream().cuda_stream), "adamw_step")
+        arena.shadow_fresh = arena.S is not None       # the kernel wrote the bf16 shadow of every element it updated
 
     def state_dict(self):
         for st in self.state.values():

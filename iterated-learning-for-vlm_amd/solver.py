@@ -94,7 +94,11 @@ class DevicePrefetcher:
     (SURVEY.md 8f-1/2): a worker thread tokenises the captions with the C++ BPE (the reference does it in Python inside
     forward(), on the training thread), pins the image batch and copies it to the device on its own stream; the
     consumer receives (image_cuda, (tokens, pad_mask, lengths)), i.e. the text tower can run on the valid tokens and
-    the H2D copy / tokenisation of batch i+1 overlap the step on batch i.  Already-tokenised text passes through."""
+    the H2D copy / tokenisation of batch i+1 overlap the step on batch i.  Already-tokenised text passes through.
+    Images may arrive as uint8 ([B,H,W,3] as decoders produce them, or [B,3,H,W]), alone or as (image_u8, flags) with
+    per-sample uint8 flags (bit 0 horizontal flip, bit 1 grayscale): the batch then crosses PCIe at a quarter of the fp32
+    size and ToTensor + Normalize (+ the flip / grayscale of MOCOV2_single) run on the device
+    (ops.image_u8_normalize; reference prototype/data/imagenet_dataloader.py:13-14,59-68)."""
 
     def __init__(self, loader, tokenize, device, depth=2):
         self.loader, self.tokenize, self.device, self.depth = loader, tokenize, torch.device(device), depth
@@ -113,9 +117,17 @@ class DevicePrefetcher:
         if isinstance(text, (list, tuple)) and text and isinstance(text[0], str):
             tokens, lengths, pad = self.tokenize(list(text), return_length=True)
             text = (tokens, pad, lengths.tolist())
+        flags = None
+        if isinstance(image, (tuple, list)):
+            image, flags = image
         if cuda:
             with torch.cuda.stream(stream):
                 image = (image if image.is_pinned() else image.pin_memory()).to(self.device, non_blocking=True)
+                if image.dtype == torch.uint8:
+                    from . import ops
+                    if flags is not None:
+                        flags = flags.to(torch.uint8).pin_memory().to(self.device, non_blocking=True)
+                    image = ops.image_u8_normalize(image.contiguous(), flags=flags)     # on this thread's current stream
                 if isinstance(text, tuple) and torch.is_tensor(text[0]):
                     text = tuple(t.pin_memory().to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in text)
                 done = torch.cuda.Event()
@@ -138,8 +150,8 @@ class DevicePrefetcher:
             except Exception as e:          # re-raised in the consumer
                 q.put(e)
 
-        t = threading.Thread(target=work, name="ilvlm-prefetch", daemon=True)
-        t.start()
+        worker = threading.Thread(target=work, name="ilvlm-prefetch", daemon=True)
+        worker.start()
         while True:
             item = q.get()
             if item is stop:
@@ -156,7 +168,7 @@ class DevicePrefetcher:
                         if torch.is_tensor(t) and t.is_cuda:
                             t.record_stream(cur)
             yield image, text
-        t.join()
+        worker.join()
 
 
 class AsyncCheckpointWriter:
