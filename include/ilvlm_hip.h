@@ -105,6 +105,13 @@ int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype
                         const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
                         int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
                         int cols, int group, int skip, float* ws, int ws_blocks, void* stream);
+/* ws (2 * |ws_blocks| * cols floats) selects the two-stage dgamma / dbeta reduction; ws_blocks < 0 DEFERS its second stage:
+ * the launch only leaves its partial rows in ws, and one ilvlm_layernorm_bwd_reduce_batched call later adds the partials of
+ * n_slots such launches (slot z at ws + z * slot_stride, same rows / |ws_blocks| / cols for all) into grad_ptrs[2z]
+ * (dgamma) and grad_ptrs[2z+1] (dbeta), a DEVICE array of 2 * n_slots pointers -- one launch per tower instead of one
+ * per LayerNorm (50 per step). */
+int ilvlm_layernorm_bwd_reduce_batched(const float* ws, long slot_stride, int n_slots, long rows, int ws_blocks, int cols,
+                                       float* const* grad_ptrs, void* stream);
 /* ws: optional workspace of 2 * ws_blocks * cols floats: per-workgroup dgamma/dbeta partials are written there and
  * summed by a second tiny kernel (deterministic, no atomic contention); ws == NULL falls back to fp32 atomics. */
 
@@ -248,8 +255,10 @@ long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);
 int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x_out, void* saved, long rows, int B, int L, int Lcap,
                     const int32_t* seq_offs, void* stream);
 /* dx_f32 / dx_lp: gradient of the block output (fp32, and its compute-dtype copy in bf16 mode); din_*: the same for the
- * block input.  ln_ws: 2 * ln_ws_blocks * E floats (LayerNorm second stage).  wgrad_target: workgroups a split-K
- * weight-gradient launch should reach (384 fills the chip). */
+ * block input.  ln_ws: 2 * ln_ws_blocks * E floats (LayerNorm second stage); ln_ws_blocks < 0 defers the second stage of
+ * both LayerNorms (ilvlm_layernorm_bwd_reduce_batched): ln_ws then holds two slots of 2 * |ln_ws_blocks| * E floats, ln_2's
+ * partials first, ln_1's second.  wgrad_target: workgroups a split-K weight-gradient launch should reach (384 fills the
+ * chip). */
 int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32, const void* dx_lp,
                     float* din_f32, void* din_lp, void* scratch, float* ln_ws, int ln_ws_blocks, long rows, int B, int L,
                     int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream);

@@ -187,6 +187,8 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     void *du = t + c.du, *dh2 = t + c.dh2, *da = t + c.da, *dqkv = t + c.dqkv, *dh1 = t + c.dh1;
     float* dmid = (float*)(t + c.dmid);
     void* dmid_lp = lp ? (void*)(t + c.dmid_lp) : nullptr;
+    // deferred LayerNorm reductions: slot 0 = ln_2, slot 1 = ln_1 (each 2 * |ln_ws_blocks| * E floats)
+    float* ln_ws1 = ln_ws_blocks < 0 ? ln_ws + 2L * (-ln_ws_blocks) * E : ln_ws;
     // MLP
     const void* dy = lp ? dx_lp : (const void*)dx_f32;
     TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg));
@@ -201,5 +203,5 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
     TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg));
     return ilvlm_layernorm_bwd(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
-                               nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, s);
+                               nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, s);
 }

@@ -1209,6 +1209,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                         : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
         if (swap && !trans_a && variant == 6)                                                                        \
             return launch_dma<TA, TB, true, 64, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);              \
+        if (swap && variant == 9)                                                                                    \
+            return launch_dma<TA, TB, true, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);             \
         return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
                     : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
     } while (0)
@@ -1243,7 +1245,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 8), "gemm_set_variant: 0, 5, 6, 7 or 8");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 9), "gemm_set_variant: 0, 5, 6, 7, 8 or 9");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }

@@ -169,7 +169,45 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// stage 2 for many LayerNorms at once: slot z holds the partial rows of one backward launch (ws + z * stride); its sums
+// go to the pointers dst[2z] (dgamma) and dst[2z+1] (dbeta).  One launch instead of one per LayerNorm.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_batched_kernel(const float* __restrict__ ws, long stride, int nblocks,
+                                                                    int cols, float* const* __restrict__ dst) {
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, by = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const int pass = blockIdx.y;
+    const float* w = ws + (long)blockIdx.z * stride;
+    float s = 0.f;
+    if (c < cols) {
+#pragma unroll 4
+        for (int b = by; b < nblocks; b += 16) s += w[((long)b * 2 + pass) * cols + c];
+    }
+    red[by][cx] = s;
+    __syncthreads();
+    if (by == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cx];
+        dst[2 * blockIdx.z + pass][c] += t;
+    }
+}
+
 }  // namespace
+
+extern "C" int ilvlm_layernorm_bwd_reduce_batched(const float* ws, long slot_stride, int n_slots, long rows, int ws_blocks,
+                                                  int cols, float* const* grad_ptrs, void* stream) {
+    ILVLM_REQUIRE(ws && grad_ptrs && n_slots > 0 && rows > 0 && ws_blocks > 0 && cols > 0, "layernorm_bwd_reduce_batched: bad args");
+    ILVLM_REQUIRE(slot_stride >= 2L * ws_blocks * cols, "layernorm_bwd_reduce_batched: slot stride %ld < 2 * %d * %d", slot_stride,
+                  ws_blocks, cols);
+    ILVLM_REQUIRE(n_slots <= 65535, "layernorm_bwd_reduce_batched: too many slots");
+    int blocks = ceil_div(rows, 4);              // what the deferred backward launches used (ilvlm_layernorm_bwd)
+    if (blocks > ws_blocks) blocks = ws_blocks;
+    hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(ceil_div(cols, 16), 2, n_slots), dim3(256), 0, (hipStream_t)stream, ws,
+                       slot_stride, blocks, cols, grad_ptrs);
+    ILVLM_LAUNCH_CHECK("layernorm_bwd_reduce_batched");
+    return ILVLM_OK;
+}
 
 extern "C" int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                                    float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
@@ -202,7 +240,10 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
     ILVLM_REQUIRE(act == 0 || ((act == ILVLM_ACT_QUICKGELU_BWD || act == ILVLM_ACT_GELU_ERF_BWD) && act_aux && dx_lp),
                   "layernorm_bwd: bad activation arguments");
     hipStream_t s = (hipStream_t)stream;
-    ILVLM_REQUIRE(ws == nullptr || ws_blocks > 0, "layernorm_bwd: ws_blocks must be positive");
+    const bool defer = ws_blocks < 0;            // partial rows only: ilvlm_layernorm_bwd_reduce_batched adds them up later
+    if (defer) ws_blocks = -ws_blocks;
+    ILVLM_REQUIRE(ws == nullptr || ws_blocks > 0, "layernorm_bwd: ws_blocks must be non-zero");
+    ILVLM_REQUIRE(!defer || ws, "layernorm_bwd: a deferred reduction needs the workspace");
     int blocks = ceil_div(rows, 4);
     const int cap = ws ? ws_blocks : 1024;
     if (blocks > cap) blocks = cap;
@@ -234,7 +275,7 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
 #undef LN_BWD
 #undef LN_BWD_NV
     ILVLM_LAUNCH_CHECK("layernorm_bwd");
-    if (ws) {
+    if (ws && !defer) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 16), 2), dim3(256), 0, s, ws, blocks, cols, dgamma, dbeta);
         ILVLM_LAUNCH_CHECK("layernorm_bwd_reduce");
     }

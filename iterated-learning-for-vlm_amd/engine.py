@@ -135,6 +135,8 @@ class Engine:
         self.composite = os.environ.get("ILVLM_COMPOSITE", "1") == "1"    # one C call per transformer block
         self.fused_fdt = os.environ.get("ILVLM_FUSED_FDT", "1") == "1"    # codebook scores + token max-pool in one GEMM
         self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
+        self.defer_ln = os.environ.get("ILVLM_DEFER_LN", "1") == "1"      # one LayerNorm-gradient reduction per tower
+        self._ln_defer = {}
         self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
     @property
@@ -286,9 +288,35 @@ class Engine:
         saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g) if save else None
         return x_out, saved
 
-    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None):
+    def _ln_defer_begin(self, tower, n_blocks, E):
+        """Deferred LayerNorm-gradient reduction for one tower's backward (composite path, no data-parallel reducer that
+        wants each block's gradients final right away): every block's two LayerNorm backward launches leave their partial
+        rows in their own slots, and ONE kernel adds all of them up at the end of the tower -- 1 launch instead of 24
+        8 us launches on the dgrad chain.  Returns the slot tensor [n_blocks, 2, 2 * LN_WS_BLOCKS * E] or None."""
+        if not (self.defer_ln and self.composite and ops._gemm_profiler is None and self.arena.reducer is None):
+            return None
+        key = (tower, n_blocks, E)
+        st = self._ln_defer.get(key)
+        if st is None:
+            pre = "visual." if tower == "v" else "encode_text."
+            ptrs = []
+            for i in range(n_blocks):
+                b = "%stransformer.resblocks.%d." % (pre, i)
+                for ln in ("ln_2", "ln_1"):                 # slot order of ilvlm_block_bwd
+                    ptrs += [self.Gr[b + ln + ".weight"].data_ptr(), self.Gr[b + ln + ".bias"].data_ptr()]
+            dev = self.arena.P.device
+            st = (torch.empty((n_blocks, 2, 2 * ops.LN_WS_BLOCKS * E), dtype=torch.float32, device=dev),
+                  torch.tensor(ptrs, dtype=torch.int64).to(dev))
+            self._ln_defer[key] = st
+        return st
+
+    def _ln_defer_end(self, st, rows, E):
+        slots, ptrs = st
+        ops.ln_reduce_batched(slots, slots.shape[2], slots.shape[0] * 2, rows, E, ptrs)
+
+    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None, ln_slots=None):
         """dx_f32: fp32 gradient of the block output; dx_lp: the same in T (None in fp32 mode).  Returns the pair
-        for the block input."""
+        for the block input.  ln_slots: this block's two deferred LayerNorm slots (composite path only)."""
         if len(saved) == 2:       # saved by the composite forward: composite backward (ilvlm_block_bwd)
             x_in, ws = saved
             M, E = x_in.shape
@@ -301,7 +329,7 @@ class Engine:
             if wg is not None:    # the scratch holds the dY operands of the weight-gradient GEMMs: alive until the join
                 self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(scratch)
                 self._wg_keep[torch.cuda.current_stream().cuda_stream].append(dx_lp if lp else dx_f32)
-            ops.block_bwd(desc, x_in, ws, dx_f32, dx_lp, din, din_lp, scratch, B, L, seq, wg)
+            ops.block_bwd(desc, x_in, ws, dx_f32, dx_lp, din, din_lp, scratch, B, L, seq, wg, ln_slots)
             return din, din_lp
         x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
         M, E = x_in.shape
@@ -364,12 +392,17 @@ class Engine:
     def vision_bwd(self, saved, dx_f32, dx_lp):
         cfg, Wf, Gr = self.cfg, self.Wf, self.Gr
         B, Lv, W = saved["B"], saved["Lv"], saved["W"]
+        composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
+        st = self._ln_defer_begin("v", cfg["v_layers"], W) if composite and all(
+            self.req["visual.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["v_layers"])) else None
         for i in reversed(range(cfg["v_layers"])):
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "visual.transformer.resblocks.%d." % i, dx_f32, dx_lp, B, Lv,
-                                           cfg["v_heads"], 0)
+                                           cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None)
             if self.arena.reducer is not None:
                 self.join_wgrad()
             self.m._sync("visual.transformer.resblocks.%d." % i)       # this block's gradients are complete
+        if st is not None:
+            self._ln_defer_end(st, B * Lv, W)
         dtok = _empty((B * Lv, W), torch.float32, dx_f32)
         ops.layernorm_bwd(dx_f32, saved["tokens"], saved["mean0"], saved["rstd0"], Wf["visual.ln_pre.weight"],
                           Gr["visual.ln_pre.weight"], Gr["visual.ln_pre.bias"], B * Lv, W, dx_f32=dtok)
@@ -438,12 +471,17 @@ class Engine:
     def text_bwd(self, saved, dx_f32, dx_lp):
         cfg, Gr = self.cfg, self.Gr
         B, Lt = saved["B"], saved["Lt"]
+        composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
+        st = self._ln_defer_begin("t", cfg["t_layers"], saved["Wt"]) if composite and all(
+            self.req["encode_text.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["t_layers"])) else None
         for i in reversed(range(cfg["t_layers"])):
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
-                                           Lt, cfg["t_heads"], 1, saved["seq"])
+                                           Lt, cfg["t_heads"], 1, saved["seq"], ln_slots=st[0][i] if st is not None else None)
             if self.arena.reducer is not None:
                 self.join_wgrad()
             self.m._sync("encode_text.transformer.resblocks.%d." % i)
+        if st is not None:
+            self._ln_defer_end(st, dx_f32.shape[0], saved["Wt"])
         need_tab, need_pos = self.req["encode_text.token_embedding.weight"], self.req["encode_text.positional_embedding"]
         if need_tab:
             ops.embed_bwd(saved["tokens"], dx_f32, Gr["encode_text.token_embedding.weight"],

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ilvlm_gemm_set_variant": [i32],
     "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
     "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp],
+    "ilvlm_layernorm_bwd_reduce_batched": [vp, i64, i32, i64, i32, i32, vp, vp],
     "ilvlm_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_embed_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],

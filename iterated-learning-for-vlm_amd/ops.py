@@ -234,13 +234,29 @@ def block_fwd(desc, x_in, x_out, saved, B, Lq, seq=None):
                                      _stream()), "block_fwd")
 
 
-def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq, seq=None, wgrad_stream=None):
+def ln_reduce_batched(ws, slot_stride, n_slots, rows, cols, grad_ptrs):
+    """second stage of n_slots deferred LayerNorm backward launches in one kernel (ilvlm_layernorm_bwd_reduce_batched)"""
+    _chk(ws, "ln_reduce.ws", torch.float32); _chk(grad_ptrs, "ln_reduce.ptrs", torch.int64, (2 * n_slots,))
+    if ws.numel() < n_slots * slot_stride:
+        raise RuntimeError("ln_reduce_batched: workspace too small")
+    L.check(L.load().ilvlm_layernorm_bwd_reduce_batched(ws.data_ptr(), slot_stride, n_slots, rows, LN_WS_BLOCKS, cols,
+                                                        grad_ptrs.data_ptr(), _stream()), "layernorm_bwd_reduce_batched")
+
+
+def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq, seq=None, wgrad_stream=None, ln_slots=None):
+    """ln_slots: fp32 tensor of 2 slots x 2 * LN_WS_BLOCKS * E floats -> the LayerNorm dgamma / dbeta second stages are
+    deferred (ln_2's partials in slot 0, ln_1's in slot 1; ln_reduce_batched adds them up); None: reduced immediately."""
     rows = x_in.shape[0]
     _chk(dx_f32, "block.dx", torch.float32, (rows, desc.E)); _chk(din_f32, "block.din", torch.float32, (rows, desc.E))
     _chk(scratch, "block.scratch", torch.uint8); _chk(saved, "block.saved", torch.uint8)
-    ws = _ln_workspace(x_in.device, desc.E)
+    if ln_slots is not None:
+        _chk(ln_slots, "block.ln_slots", torch.float32)
+        if ln_slots.numel() < 4 * LN_WS_BLOCKS * desc.E:
+            raise RuntimeError("block_bwd: ln_slots too small")
+    ws = ln_slots if ln_slots is not None else _ln_workspace(x_in.device, desc.E)
     L.check(L.load().ilvlm_block_bwd(C.byref(desc), x_in.data_ptr(), saved.data_ptr(), dx_f32.data_ptr(), _p(dx_lp),
-                                     din_f32.data_ptr(), _p(din_lp), scratch.data_ptr(), ws.data_ptr(), LN_WS_BLOCKS, rows,
+                                     din_f32.data_ptr(), _p(din_lp), scratch.data_ptr(), ws.data_ptr(),
+                                     -LN_WS_BLOCKS if ln_slots is not None else LN_WS_BLOCKS, rows,
                                      B, Lq, seq.cap if seq is not None else Lq,
                                      seq.offs.data_ptr() if seq is not None else None, _WGRAD_TARGET, _stream(),
                                      None if wgrad_stream is None else wgrad_stream.cuda_stream), "block_bwd")
