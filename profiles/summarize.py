@@ -29,7 +29,7 @@ def main():
     shutil.copy(stats, os.path.join(a.dst, "kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --serial-towers",
+    lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-roofline --no-dense-leg --steps 20 --warmup 5 --serial-towers",
              "# (towers serialised so per-kernel durations are those of a kernel owning the chip; the headline run overlaps them)",
              "# GPU busy per train step: %.2f ms  (%d steps)" % (total / a.steps / 1e6, a.steps), "",
              "%7s %9s %10s %10s  %s" % ("share", "calls/st", "avg us", "ms/step", "kernel")]
@@ -37,6 +37,41 @@ def main():
         lines.append("%6.2f%% %9.1f %10.1f %10.3f  %s" % (float(r["Percentage"]), int(r["Calls"]) / a.steps,
                                                           float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / a.steps / 1e6,
                                                           short(r["Name"])))
+    conc = glob.glob(os.path.join(a.src, "stats_concurrent", "*", "*_kernel_stats.csv"))
+    if conc:
+        shutil.copy(conc[0], os.path.join(a.dst, "kernel_stats_concurrent.csv"))
+        crows = list(csv.DictReader(open(conc[0])))
+        ctotal = sum(float(r["TotalDurationNs"]) for r in crows)
+        lines += ["", "# the same command WITHOUT --serial-towers (headline regime: towers and weight gradients on their own streams;",
+                  "# launches overlap, so durations are inflated and their sum exceeds the step time).  Sum of durations per step: %.2f ms"
+                  % (ctotal / a.steps / 1e6), "%7s %9s %10s %10s  %s" % ("share", "calls/st", "avg us", "ms/step", "kernel")]
+        for r in crows[:12]:
+            lines.append("%6.2f%% %9.1f %10.1f %10.3f  %s" % (float(r["Percentage"]), int(r["Calls"]) / a.steps,
+                                                              float(r["AverageNs"]) / 1e3,
+                                                              float(r["TotalDurationNs"]) / a.steps / 1e6, short(r["Name"])))
+    mf = glob.glob(os.path.join(a.src, "mfma", "*", "*_counter_collection.csv"))
+    if mf:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        cnt = collections.Counter()
+        for r in csv.DictReader(open(mf[0])):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[k] += 1
+        lines += ["", "# MFMA utilisation from PMC counters (one pass): MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs),",
+                  "# the rocprofv3 MfmaUtil expression; GRBM_GUI_ACTIVE is summed over the 8 XCDs by rocprofv3 (MI355X_MICROARCH.md),",
+                  "# so busy cycles are set against (GRBM_GUI_ACTIVE / 8) x 1024 SIMDs.  MFMA FLOPs = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512.",
+                  "%-40s %10s %14s %10s" % ("kernel", "MfmaUtil %", "GFLOP/launch", "launches")]
+        mout = {}
+        for k in sorted(agg, key=lambda k: -agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:8]:
+            busy, gui = agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), agg[k].get("GRBM_GUI_ACTIVE", 0.0)
+            if gui <= 0 or busy <= 0:
+                continue
+            util = 100.0 * busy / (gui / 8.0 * 1024.0)
+            gfl = agg[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / max(cnt[k], 1) / 1e9
+            mout[k] = dict(mfma_util_pct=util, mfma_gflop_per_launch=gfl, launches=cnt[k])
+            lines.append("%-40s %10.1f %14.2f %10d" % (k, util, gfl, cnt[k]))
+        json.dump(mout, open(os.path.join(a.dst, "mfma_util.json"), "w"), indent=1)
     traffic = {}
     for what in ("fetch", "write"):
         f = glob.glob(os.path.join(a.src, what, "*", "*_counter_collection.csv"))
