@@ -1,0 +1,35 @@
+"""fp8 vs bf16 direct-to-LDS GEMM on the forward / input-gradient shapes of the step (cold caches)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ilvlm_amd import ops
+
+flush = torch.empty(128 * 1024 * 1024, device="cuda")
+one = torch.ones(1, device="cuda")
+
+
+def t_of(fn, rounds=6):
+    best = 1e9
+    for _ in range(rounds):
+        flush.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best * 1e3
+
+
+tot = [0.0, 0.0]
+for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
+    for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E), ("qkv.dgrad", E, 3 * E), ("fc.dgrad", E, 4 * E),
+                       ("proj.dgrad", 4 * E, E)):
+        a = torch.randn(M, k, device="cuda").to(torch.bfloat16); w = torch.randn(n, k, device="cuda").to(torch.bfloat16)
+        a8 = torch.randint(0, 120, (M, k), device="cuda", dtype=torch.uint8); w8 = torch.randint(0, 120, (n, k), device="cuda", dtype=torch.uint8)
+        out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
+        tb = t_of(lambda: ops.gemm(a, w, out))
+        t8 = t_of(lambda: ops.gemm_fp8(a8, w8, out, one, one))
+        fl = 2.0 * M * n * k
+        tot[0] += tb; tot[1] += t8
+        print("%-14s M=%6d N=%5d K=%5d  bf16 %6.1f us %5.0f TF   fp8 %6.1f us %5.0f TF   x%.2f" % (
+            tag + "." + name, M, n, k, tb, fl / tb / 1e6, t8, fl / t8 / 1e6, tb / t8), flush=True)
+print("sum bf16 %.0f us, fp8 %.0f us, x%.2f" % (tot[0], tot[1], tot[0] / tot[1]))

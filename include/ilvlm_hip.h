@@ -28,7 +28,9 @@ extern "C" {
 #define ILVLM_VERSION 100 /* round 1 */
 
 enum { ILVLM_OK = 0, ILVLM_ERR_ARG = -1 };
-enum { ILVLM_F32 = 0, ILVLM_BF16 = 1 };
+enum { ILVLM_F32 = 0, ILVLM_BF16 = 1,
+       ILVLM_FP8 = 2,      /* GEMM compute dtype: A and B are OCP fp8 e4m3 bytes                                       */
+       ILVLM_FP8_BF8A = 3  /* GEMM compute dtype: A is OCP fp8 e5m2 (gradients), B is e4m3                             */ };
 enum {
     ILVLM_ACT_NONE = 0,
     ILVLM_ACT_QUICKGELU = 1,     /* out = x*sigmoid(1.702x); pre-activation stored to aux  (base_transformer.py:24-26) */
@@ -51,6 +53,9 @@ const char* ilvlm_last_error(void);
  *     its weight gradient = (1,1) with A = dY, B = X, accumulate = 1.
  * compute_dtype ILVLM_BF16: A,B bf16 -> v_mfma_f32_16x16x32_bf16, fp32 accumulate.
  * compute_dtype ILVLM_F32 : A,B f32  -> v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+ * compute_dtype ILVLM_FP8 / ILVLM_FP8_BF8A: A,B fp8 bytes (OCP e4m3; _BF8A: A is e5m2) -> v_mfma_f32_16x16x32_fp8_*,
+ *   fp32 accumulate; (0,0) layout only, K % 128 == 0, lda / ldb in elements (= bytes); the de-quantisation scales go
+ *   through alpha_ptr / alpha_ptr2; aux (activation epilogues) is bf16, out is bf16 or fp32 (BASELINE configs[4]).
  * Epilogue, in this order: acc *= alpha * (alpha_ptr ? *alpha_ptr : 1); += bias[n];
  *   += rowbias[(out_skip + m % out_group) * N + n]; activation (see ILVLM_ACT_*; aux is [M,N] with
  *   stride ldc, dtype = compute_dtype); += residual (fp32, laid out like C); store as out_dtype
@@ -83,6 +88,7 @@ typedef struct ilvlm_gemm_epilogue {
     const int32_t* pool_seq;
     const int32_t* pool_offs;
     int pool_group;
+    const float* alpha_ptr2; /* second device scalar multiplied into alpha (fp8: the two de-quantisation scales) or NULL */
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
@@ -188,6 +194,20 @@ int ilvlm_infonce_fwd(const float* logits_i, const float* logits_t, int B, int B
                       float* dlogits_i, float* dlogits_t, void* stream);
 /* accuracy() of misc.py:464-477: out[0] = 100/B * #{rows whose label is in the top-1}, out[1] same for top-k */
 int ilvlm_topk_accuracy(const float* logits, int B, int Bg, int label_offset, int k, float* out, void* stream);
+
+/* ---- fp8 path (BASELINE.json configs[4]; no counterpart in the reference, whose nn.Linear calls are fp32:
+ * image_encoder/base_transformer.py:35-48).  Per-tensor delayed scaling: q = saturate(x * scale[slot]) in OCP e4m3
+ * (fmt 0, activations and weights) or e5m2 (fmt 1, gradients); every quantising call also raises amax[slot] to max|x| of
+ * what it saw; ilvlm_fp8_scale_update turns the amax history of each slot into next step's scale (fmt_max / max(history))
+ * and its inverse (the GEMM's alpha_ptr / alpha_ptr2).  dst == NULL observes amax without quantising. */
+int ilvlm_fp8_quantize(const void* src, int src_dtype, void* dst, long n, const float* scale, float* amax, int fmt, void* stream);
+/* all GEMM weights of the towers in one launch: tile_table holds 6 ints per 64 x 64 tile {arena offset / 64, rows, cols,
+ * scale slot, tile row, tile col}; w8 receives the e4m3 weight in its own [rows, cols] layout (forward operand), w8t its
+ * transpose [cols, rows] (input-gradient operand), both at the tensor's offset in an arena-shaped byte buffer. */
+int ilvlm_fp8_quantize_weights(const float* params, void* w8, void* w8t, const int32_t* tile_table, int n_tiles,
+                               const float* scale, float* amax, void* stream);
+int ilvlm_fp8_scale_update(float* amax_cur, float* hist, float* scale, float* inv_scale, const float* fmt_max, int n_slots,
+                           int hist_len, int pos, void* stream);
 
 /* ---- input pipeline: uint8 image batch -> normalised fp32 NCHW on the device.
  * dst[b,c,y,x] = (src(b,c,y,x') / 255 - mean[c]) / std[c], i.e. transforms.ToTensor + transforms.Normalize of

@@ -559,7 +559,13 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
 }
 #endif
 
-template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT>
+// FP8 = 0: bf16 operands.  FP8 = 1 / 2: fp8 operands (OCP e4m3; 2: the A operand is e5m2, for gradients) addressed as if two
+// fp8 elements were one bf16 element -- the host passes K / 2, lda / 2, ldb / 2 -- so tiles, DMA and the LDS images are
+// byte for byte those of the bf16 kernel with a K-tile of 128 instead of 64; only the MFMA differs: every 16-byte
+// fragment read feeds two v_mfma_f32_16x16x32_fp8 (8 bytes = 8 k each; both operands split their bytes the same way, so
+// the products pair up whatever order k is visited in).  Half the operand bytes per FLOP of the bf16 kernel, which is
+// what bounds it.  K-contiguous operands only.
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT, int FP8 = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
                                                                      const bf16* __restrict__ B, int ldb, int K, int tiles_m,
                                                                      int tiles_n, int split_k, EpiArgs ep) {
@@ -674,8 +680,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)      // C^T fragments: lane owns row (l & 15), 4 consecutive columns
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) {    // C^T fragments: lane owns row (l & 15), 4 consecutive columns
+                    if constexpr (FP8 == 0) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    } else {
+                        union { bf16x8 v; long l[2]; } ua, ub;
+                        ua.v = fa[i]; ub.v = fb[j];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            if constexpr (FP8 == 1)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ub.l[hh], ua.l[hh], acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(ub.l[hh], ua.l[hh], acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
             if (rowsum) {                         // every register of lane c = row sum of operand row c
 #pragma unroll
                 for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accb[i], 0, 0, 0);
@@ -708,6 +727,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 
     float alpha = ep.e.alpha;
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
     const int mw = m0 + wm * (TI * 16), nw = n0 + wn * (TJ * 16);
 #if ILVLM_GEMM_ABLATE == 3
     if (acc[0][0][0] != 12345.678f) return;
@@ -1085,9 +1105,9 @@ int launch_bf16(const bf16* A, int lda, const bf16* B, int ldb, int K, int tm, i
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT = 64>
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT = 64, int FP8 = 0>
 int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT>;
+    auto kern = gemm_bf16_dma_kernel<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT, FP8>;
     // operand ring; the SWAP epilogue transposes through 8 KiB per wave of the same allocation
     constexpr int ring = NSTAGE * (DBM + DBN) * BKT * 2, epi = WM * WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
@@ -1140,7 +1160,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                           void* stream) {
     ILVLM_REQUIRE(A && B && C && epi, "gemm: null pointer");
     ILVLM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    ILVLM_REQUIRE(compute_dtype == ILVLM_F32 || compute_dtype == ILVLM_BF16, "gemm: bad compute dtype %d", compute_dtype);
+    ILVLM_REQUIRE(compute_dtype == ILVLM_F32 || compute_dtype == ILVLM_BF16 || compute_dtype == ILVLM_FP8 ||
+                      compute_dtype == ILVLM_FP8_BF8A, "gemm: bad compute dtype %d", compute_dtype);
     ILVLM_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? N : K) && ldc >= N, "gemm: leading dimension too small");
     ILVLM_REQUIRE(split_k >= 1, "gemm: split_k must be >= 1");
     ILVLM_REQUIRE(split_k == 1 || epi->accumulate, "gemm: split_k > 1 needs accumulate");
@@ -1148,6 +1169,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                   "gemm: accumulate excludes the other epilogue terms");
     ILVLM_REQUIRE(!(epi->accumulate && epi->out_dtype != ILVLM_F32), "gemm: accumulate needs fp32 output");
     ILVLM_REQUIRE(!(compute_dtype == ILVLM_F32 && epi->out_dtype != ILVLM_F32), "gemm: fp32 compute writes fp32");
+    const bool fp8 = compute_dtype == ILVLM_FP8 || compute_dtype == ILVLM_FP8_BF8A;
+    ILVLM_REQUIRE(!fp8 || (!trans_a && !trans_b && !epi->accumulate && !epi->a_rowsum && !epi->pool_out && K % 128 == 0 &&
+                           lda % 16 == 0 && ldb % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0),
+                  "gemm fp8: K-contiguous operands only (trans_a = trans_b = 0), no accumulate, K %% 128 == 0, 16-byte aligned rows");
     ILVLM_REQUIRE(!(epi->act && !epi->aux), "gemm: activation needs aux");
     ILVLM_REQUIRE(!(epi->rowbias && epi->out_group <= 0), "gemm: rowbias needs out_group");
     ILVLM_REQUIRE(epi->act >= 0 && epi->act <= ILVLM_ACT_GELU_ERF_BWD, "gemm: bad act %d", epi->act);
@@ -1167,6 +1192,16 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ep.N = N;
     size_t caln = epi->out_dtype == ILVLM_F32 ? 16 : 8;
     size_t auxaln = compute_dtype == ILVLM_F32 ? 16 : 8;
+    if (fp8) {      // two fp8 elements are addressed as one bf16 element (gemm_bf16_dma_kernel, FP8)
+        ep.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && aligned(C, caln) && (!epi->bias || aligned(epi->bias, 16)) &&
+                    (!epi->rowbias || aligned(epi->rowbias, 16)) && (!epi->residual || aligned(epi->residual, 16)) &&
+                    (!epi->aux || aligned(epi->aux, auxaln));
+        if (compute_dtype == ILVLM_FP8)
+            return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N,
+                                                                           1, ep, s);
+        return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 2>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N, 1,
+                                                                       ep, s);
+    }
     ep.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && aligned(C, caln) && (!epi->bias || aligned(epi->bias, 16)) &&
                 (!epi->rowbias || aligned(epi->rowbias, 16)) && (!epi->residual || aligned(epi->residual, 16)) &&
                 (!epi->aux || aligned(epi->aux, auxaln));

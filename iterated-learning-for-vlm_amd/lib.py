@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libilvlm_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8, FP8_BF8A = 0, 1, 2, 3
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_QUICKGELU_BWD, ACT_GELU_ERF_BWD = 0, 1, 2, 3, 4
 POOL_MAX, POOL_MEAN, POOL_SUM = 0, 1, 2
 
@@ -17,7 +17,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("rowbias", vp), ("residual", vp), ("aux", vp), ("alpha_ptr", vp),
                 ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
                 ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp),
-                ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32)]
+                ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32), ("alpha_ptr2", vp)]
 
 
 class Block(C.Structure):
@@ -63,6 +63,9 @@ SIGNATURES = {
     "ilvlm_infonce_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "ilvlm_topk_accuracy": [vp, i32, i32, i32, i32, vp, vp],
     "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
+    "ilvlm_fp8_quantize": [vp, i32, vp, i64, vp, vp, i32, vp],
+    "ilvlm_fp8_quantize_weights": [vp, vp, vp, vp, i32, vp, vp, vp],
+    "ilvlm_fp8_scale_update": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_image_u8_normalize": [vp, i32, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
     "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
     "ilvlm_cast_to_f32": [vp, i32, vp, i64, vp],

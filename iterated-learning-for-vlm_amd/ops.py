@@ -145,6 +145,47 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
     return out
 
 
+def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual=None, aux=None, act=0):
+    """out[m,n] = epilogue(inv_a * inv_b * sum_k a8[m,k] b8[n,k]); a8 [M,K], b8 [N,K] uint8 holding OCP fp8 (e4m3; a8
+    e5m2 with a_e5m2), scale_a / scale_b: 1-element fp32 device tensors with the de-quantisation factors."""
+    _chk(a8, "gemm_fp8.a", torch.uint8); _chk(b8, "gemm_fp8.b", torch.uint8); _chk(out, "gemm_fp8.out")
+    m, k = a8.shape
+    n = b8.shape[0]
+    if b8.shape[1] != k or tuple(out.shape) != (m, n):
+        raise RuntimeError("gemm_fp8: shapes %s %s -> %s" % (tuple(a8.shape), tuple(b8.shape), tuple(out.shape)))
+    if bias is not None:
+        _chk(bias, "gemm_fp8.bias", torch.float32, (n,))
+    if residual is not None:
+        _chk(residual, "gemm_fp8.residual", torch.float32, out.shape)
+    if aux is not None:
+        _chk(aux, "gemm_fp8.aux", torch.bfloat16, (m, n))
+    epi = GemmEpilogue(_p(bias), None, _p(residual), _p(aux), scale_a.data_ptr(), 1.0, int(act), dt(out), 0, 0, 0, None,
+                       None, None, None, 0, scale_b.data_ptr())
+    prof = _gemm_profiler
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        ev0.record(est)
+    L.check(L.load().ilvlm_gemm(L.FP8_BF8A if a_e5m2 else L.FP8, 0, 0, m, n, k, a8.data_ptr(), a8.stride(0), b8.data_ptr(),
+                                b8.stride(0), out.data_ptr(), out.stride(0), C.byref(epi), 1, _stream()), "gemm(fp8)")
+    if prof is not None:
+        ev1.record(est)
+        nbytes = 1.0 * (m * k + n * k) + m * n * out.element_size() + m * n * (4 if residual is not None else 0) + (
+            m * n * 2 if aux is not None else 0)
+        prof.records.append((ev0, ev1, 2.0 * m * n * k, nbytes))
+    return out
+
+
+def fp8_quantize(src, dst, scale, amax, e5m2=False):
+    """dst (uint8, same shape; None = observe only) = fp8(src * scale[0]); amax[0] = max(amax[0], max|src|)"""
+    _chk(src, "fp8_quantize.src")
+    if dst is not None:
+        _chk(dst, "fp8_quantize.dst", torch.uint8, src.shape)
+    L.check(L.load().ilvlm_fp8_quantize(src.data_ptr(), dt(src), _p(dst), src.numel(), _p(scale), _p(amax), int(bool(e5m2)),
+                                        _stream()), "fp8_quantize")
+    return dst
+
+
 def gemm_set_variant(v):
     L.check(L.load().ilvlm_gemm_set_variant(int(v)), "gemm_set_variant")
 
