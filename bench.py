@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 # fwd+bwd algorithmic FLOPs per pair
 FLOPS_PER_PAIR = {"vitb32": 45.9e9, "vitl14": 531.1e9}
 PEAK_BF16 = 2500.0             # TFLOP/s dense bf16 MFMA, MI355X (MI355X_MICROARCH.md)
+PEAK_FP8 = 5000.0              # TFLOP/s dense fp8 MFMA (block-scaled forms; the non-scaled fp8 MFMA used here issues at the bf16 rate)
 
 
 def parse():
@@ -34,7 +35,9 @@ def parse():
     ap.add_argument("--model", default="vitb32", choices=["vitb32", "vitl14"],
                     help="vitb32 = the headline workload (BASELINE.json configs[1]/[2]); vitl14 = configs[3], ViT-L/14 + FDT, "
                          "an extra data point that is never the default")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="bf16 = the headline (BASELINE configs[1]/[2]); fp8 = configs[4]: QKV / out / MLP GEMMs forward + input "
+                         "gradient on OCP fp8 operands with per-tensor delayed scaling, everything else as bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--all-text-positions", action="store_true",
@@ -271,7 +274,7 @@ def main():
     # ---- roofline legs (every rank runs the same steps; rank 0 reports)
     roofline = None
     executed_flops = None
-    if not args.no_roofline and args.precision == "bf16":
+    if not args.no_roofline and args.precision in ("bf16", "fp8"):
         nprof = 2
         legs = {}
         for leg, conc in (("serial", False), ("in_step", True)):
@@ -328,6 +331,15 @@ def main():
                                          gemm_sum_of_durations_ms_per_step=round(c["ms"] / nprof, 3),
                                          achieved=round(c["flops"] / (c["union_ms"] * 1e-3) / 1e12, 2),
                                          frac=round(c["flops"] / (c["union_ms"] * 1e-3) / 1e12 / PEAK_BF16, 4)))
+            if args.precision == "fp8" and s["fp8"]["launches"]:
+                f8 = s["fp8"]
+                a8 = f8["flops"] / (f8["ms"] * 1e-3) / 1e12
+                roofline["fp8_family"] = dict(
+                    kernel="gemm_bf16_dma_kernel<..., FP8> (forward + input-gradient GEMMs of the transformer blocks on OCP fp8 "
+                           "operands, v_mfma_f32_16x16x32_fp8_*); the other launches counted above are bf16",
+                    achieved=round(a8, 2), peak=PEAK_FP8, frac=round(a8 / PEAK_FP8, 4), launches_per_step=f8["launches"] // nprof,
+                    ms_per_step=round(f8["ms"] / nprof, 3), algorithmic_gflop_per_step=round(f8["flops"] / nprof / 1e9, 1),
+                    algorithmic_bytes_per_launch=round(f8["bytes"] / f8["launches"]))
     if args.phase_times:                 # every rank runs the steps (matched collectives); rank 0 prints
         model._phase_marks = []
         for _ in range(5):
@@ -350,7 +362,7 @@ def main():
         if rank == 0:
             print("phase %-40s %7.3f ms" % ("host enqueue of one step, GPU idle", sorted(hs)[2]), file=sys.stderr, flush=True)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "vitb32":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "vitb32" and args.precision != "fp8":
         cpu = cpu_baseline()
     if world > 1:
         dist.barrier()

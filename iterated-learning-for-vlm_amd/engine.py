@@ -47,7 +47,7 @@ class ParamArena:
         self.total = off
         self.P = torch.zeros(off, device=dev, dtype=torch.float32)
         self.G = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.S = torch.zeros(off, device=dev, dtype=torch.bfloat16) if precision == "bf16" else None
+        self.S = torch.zeros(off, device=dev, dtype=torch.bfloat16) if precision in ("bf16", "fp8") else None
         self.views, self.gviews, self.sviews = {}, {}, {}
         self.inactive = set()     # parameters the loss never reaches (no gradient, untouched by the optimizer)
         self.shadow_fresh = False # set by the fused optimizer: its kernel wrote the bf16 shadow of what it updated
@@ -109,6 +109,84 @@ class ParamArena:
         return self.offsets[names[0]], self.offsets[last] + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
 
 
+class Fp8State:
+    """Per-tensor delayed scaling for the fp8 mode (BASELINE.json configs[4]): the QKV / out / MLP GEMMs of both towers run
+    on fp8 operands in the forward pass (activations and weights e4m3) and in the input-gradient pass (gradients e5m2,
+    transposed e4m3 weights); weight gradients stay bf16.  Every quantised tensor kind has a SLOT: its scale is derived
+    from the amax history of the last HIST steps (ilvlm_fp8_scale_update); the first step runs the bf16 kernels and only
+    observes the amaxes (there is no history to scale by yet)."""
+    HIST = 16
+    ACT, GRAD, WEIGHT = ("h1", "att", "h2", "g"), ("dout", "du", "dmid", "dqkv"), ("in_w", "out_w", "fc_w", "proj_w")
+    WNAME = dict(in_w="attn.in_proj_weight", out_w="attn.out_proj.weight", fc_w="mlp.c_fc.weight", proj_w="mlp.c_proj.weight")
+
+    def __init__(self, arena, block_prefixes):
+        dev = arena.P.device
+        self.arena = arena
+        self.slots = {}
+        fmt_max = []
+        table = []
+        for pre in block_prefixes:
+            for k in self.ACT + self.WEIGHT:
+                self.slots[pre + k] = len(fmt_max); fmt_max.append(448.0)
+            for k in self.GRAD:
+                self.slots[pre + k] = len(fmt_max); fmt_max.append(57344.0)
+            for k in self.WEIGHT:
+                name = pre + self.WNAME[k]
+                r, c = arena.views[name].shape
+                if r % 64 or c % 64 or arena.offsets[name] % 64:
+                    raise RuntimeError("fp8 mode: weight %s [%d,%d] is not a multiple of 64 x 64" % (name, r, c))
+                for r0 in range(0, r, 64):
+                    for c0 in range(0, c, 64):
+                        table.append((arena.offsets[name] // 64, r, c, self.slots[pre + k], r0, c0))
+        n = len(fmt_max)
+        self.n = n
+        self.fmt_max = torch.tensor(fmt_max, dtype=torch.float32).to(dev)
+        self.amax = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.hist = torch.zeros((n, self.HIST), dtype=torch.float32, device=dev)
+        self.scale = torch.ones(n, dtype=torch.float32, device=dev)
+        self.inv = torch.ones(n, dtype=torch.float32, device=dev)
+        self.table = torch.tensor(table, dtype=torch.int32).to(dev)
+        self.W8 = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
+        self.W8T = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
+        self.steps = 0            # scale updates done; 0 = nothing observed yet
+        self.active = False       # False: observe only (bf16 GEMMs); True: fp8 GEMMs
+
+    def begin_step(self, training):
+        """once per forward: activations / gradients of the previous step -> scales; weights re-quantised from the masters"""
+        lib = ops.L.load()
+        st = ops._stream()
+        if self.steps == 0:       # weights: observe their amax first so that the very first quantisation is scaled
+            ops.L.check(lib.ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
+                                                       self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
+                                                       self.amax.data_ptr(), st), "fp8_quantize_weights")
+        ops.L.check(lib.ilvlm_fp8_scale_update(self.amax.data_ptr(), self.hist.data_ptr(), self.scale.data_ptr(),
+                                               self.inv.data_ptr(), self.fmt_max.data_ptr(), self.n, self.HIST,
+                                               self.steps % self.HIST, st), "fp8_scale_update")
+        ops.L.check(lib.ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
+                                                   self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
+                                                   self.amax.data_ptr(), st), "fp8_quantize_weights")
+        self.active = self.steps >= 1          # activation / gradient slots have a history from the second step on
+        self.steps += 1
+
+    def s(self, key):
+        i = self.slots[key]
+        return self.scale[i:i + 1], self.inv[i:i + 1], self.amax[i:i + 1]
+
+    def w8(self, pre, k, transposed=False):
+        name = pre + self.WNAME[k]
+        o = self.arena.offsets[name]
+        r, c = self.arena.views[name].shape
+        return (self.W8T[o:o + r * c].view(c, r) if transposed else self.W8[o:o + r * c].view(r, c))
+
+    def quant(self, x, key, e5m2=False):
+        """fp8 copy of x for slot `key` (None while only observing); always records the amax"""
+        sc, _, am = self.s(key)
+        if not self.active:
+            ops.fp8_quantize(x, None, None, am, e5m2)
+            return None
+        return ops.fp8_quantize(x, torch.empty(x.shape, dtype=torch.uint8, device=x.device), sc, am, e5m2)
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -121,9 +199,12 @@ class Engine:
         self.m = module
         self.cfg = cfg
         self.precision = cfg["precision"]
-        if self.precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (self.precision,))
-        self.T = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        if self.precision not in ("bf16", "fp32", "fp8"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8', got %r" % (self.precision,))
+        # fp8: bf16 storage and kernels everywhere except the QKV / out / MLP GEMMs (forward + input gradient), which take
+        # fp8 operands with per-tensor delayed scaling (Fp8State)
+        self.T = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        self.fp8 = None
         self.arena = None
         self._side = None
         self.concurrent_towers = True     # False: everything on the current stream (per-kernel timing, debugging)
@@ -170,8 +251,14 @@ class Engine:
         a.shadow_fresh = False
         a._versions = vers
         self.Wf = a.views                                     # fp32 masters
-        self.Wc = a.sviews if self.precision == "bf16" else a.views   # GEMM operands
+        self.Wc = a.views if self.precision == "fp32" else a.sviews   # GEMM operands
         self.Gr = a.gviews
+        if self.precision == "fp8":
+            if self.fp8 is None:
+                pres = ["visual.transformer.resblocks.%d." % i for i in range(self.cfg["v_layers"])] + \
+                       ["encode_text.transformer.resblocks.%d." % i for i in range(self.cfg["t_layers"])]
+                self.fp8 = Fp8State(a, pres)
+            self.fp8.begin_step(True)
         req = {n: p.requires_grad for n, p in a.named}
         if req != getattr(self, "req", None):
             self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots
@@ -205,7 +292,7 @@ class Engine:
         """ilvlm_block descriptor of the transformer block with parameter prefix `pre`, or None when the composite path
         does not apply: switched off (ILVLM_COMPOSITE=0), a GEMM profiler is attached (it times the individual launches),
         or a LayerNorm parameter of the block is frozen."""
-        if not self.composite or ops._gemm_profiler is not None:
+        if not self.composite or ops._gemm_profiler is not None or self.fp8 is not None:
             return None
         d = self._blk.get(pre)
         if d is None:
@@ -227,8 +314,10 @@ class Engine:
         return w if w.dim() == 2 else w.reshape(w.shape[0], -1)
 
     # ------------------------------------------------------------------ helpers
-    def _linear_bwd(self, dy, x, wname, bname, need_dx=True, dx_act=0, dx_aux=None):
-        """dy: [M,N] T; x: [M,K] T.  Accumulates dW (and db) into the gradient arena, returns dx (T) or None."""
+    def _linear_bwd(self, dy, x, wname, bname, need_dx=True, dx_act=0, dx_aux=None, fp8_keys=None):
+        """dy: [M,N] T; x: [M,K] T.  Accumulates dW (and db) into the gradient arena, returns dx (T) or None.
+        fp8_keys = (block prefix, gradient slot, weight slot): the input gradient runs on e5m2 x transposed-e4m3 operands
+        in fp8 mode (the weight gradient stays in the compute dtype)."""
         M, N = dy.shape
         K = x.shape[1]
         need_b = bname is not None and self.req[bname]
@@ -256,7 +345,15 @@ class Engine:
         if not need_dx:
             return None
         dx = _empty((M, K), self.T, dy)
-        ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act)
+        dy8 = None
+        if fp8_keys is not None and self.fp8 is not None:
+            pre, kg, kw_ = fp8_keys
+            dy8 = self.fp8.quant(dy, pre + kg, e5m2=True)
+        if dy8 is not None:
+            ops.gemm_fp8(dy8, self.fp8.w8(pre, kw_, transposed=True), dx, self.fp8.s(pre + kg)[1], self.fp8.s(pre + kw_)[1],
+                         a_e5m2=True, aux=dx_aux, act=dx_act)
+        else:
+            ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act)
         return dx
 
     # ------------------------------------------------------------------ transformer block
@@ -271,20 +368,30 @@ class Engine:
             return x_out, ((x_in, ws) if save else None)
         T = self.T
         Wf = self.Wf
+        f8 = self.fp8
+
+        def lin(x, key_a, key_w, wname, out, **kw):
+            """x [M,K] (T) . W^T: fp8 operands when the fp8 mode is active, else the compute-dtype GEMM"""
+            x8 = f8.quant(x, pre + key_a) if f8 is not None else None
+            if x8 is not None:
+                ops.gemm_fp8(x8, f8.w8(pre, key_w), out, f8.s(pre + key_a)[1], f8.s(pre + key_w)[1], **kw)
+            else:
+                ops.gemm(x, self._mat(pre + wname), out, **kw)
+
         h1 = _empty((M, E), T, x_in); mean1 = _empty((M,), torch.float32, x_in); rstd1 = torch.empty_like(mean1)
         ops.layernorm_fwd(x_in, Wf[pre + "ln_1.weight"], Wf[pre + "ln_1.bias"], h1, mean1, rstd1, M, E)
         qkv = _empty((M, 3 * E), T, x_in)
-        ops.gemm(h1, self._mat(pre + "attn.in_proj_weight"), qkv, bias=Wf[pre + "attn.in_proj_bias"])
+        lin(h1, "h1", "in_w", "attn.in_proj_weight", qkv, bias=Wf[pre + "attn.in_proj_bias"])
         att = _empty((M, E), T, x_in); lse = _empty((B, H, L), torch.float32, x_in)
         ops.attention_fwd(qkv, att, lse, B, L, H, causal, seq)
         x_mid = _empty((M, E), torch.float32, x_in)
-        ops.gemm(att, self._mat(pre + "attn.out_proj.weight"), x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
+        lin(att, "att", "out_w", "attn.out_proj.weight", x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
         h2 = _empty((M, E), T, x_in); mean2 = torch.empty_like(mean1); rstd2 = torch.empty_like(mean1)
         ops.layernorm_fwd(x_mid, Wf[pre + "ln_2.weight"], Wf[pre + "ln_2.bias"], h2, mean2, rstd2, M, E)
         u = _empty((M, 4 * E), T, x_in); g = _empty((M, 4 * E), T, x_in)
-        ops.gemm(h2, self._mat(pre + "mlp.c_fc.weight"), g, bias=Wf[pre + "mlp.c_fc.bias"], aux=u, act=ACT_QUICKGELU)
+        lin(h2, "h2", "fc_w", "mlp.c_fc.weight", g, bias=Wf[pre + "mlp.c_fc.bias"], aux=u, act=ACT_QUICKGELU)
         x_out = _empty((M, E), torch.float32, x_in)
-        ops.gemm(g, self._mat(pre + "mlp.c_proj.weight"), x_out, bias=Wf[pre + "mlp.c_proj.bias"], residual=x_mid)
+        lin(g, "g", "proj_w", "mlp.c_proj.weight", x_out, bias=Wf[pre + "mlp.c_proj.bias"], residual=x_mid)
         saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g) if save else None
         return x_out, saved
 
@@ -337,18 +444,19 @@ class Engine:
         lp = T != torch.float32
         dy = dx_lp if lp else dx_f32
         # MLP: x_out = x_mid + c_proj(quickgelu(c_fc(h2)))
-        du = self._linear_bwd(dy, g, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dx_act=ACT_QUICKGELU_BWD, dx_aux=u)
-        dh2 = self._linear_bwd(du, h2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias")
+        du = self._linear_bwd(dy, g, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dx_act=ACT_QUICKGELU_BWD, dx_aux=u,
+                              fp8_keys=(pre, "dout", "proj_w"))
+        dh2 = self._linear_bwd(du, h2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", fp8_keys=(pre, "du", "fc_w"))
         dmid = _empty((M, E), torch.float32, x_in)
         dmid_lp = _empty((M, E), T, x_in) if lp else None
         ops.layernorm_bwd(dh2, x_mid, mean2, rstd2, Wf[pre + "ln_2.weight"], Gr[pre + "ln_2.weight"], Gr[pre + "ln_2.bias"],
                           M, E, dres=dx_f32, dx_f32=dmid, dx_lp=dmid_lp)
         dy = dmid_lp if lp else dmid
         # attention: x_mid = x_in + out_proj(attn(in_proj(h1)))
-        da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias")
+        da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias", fp8_keys=(pre, "dmid", "out_w"))
         dqkv = _empty((M, 3 * E), T, x_in)
         ops.attention_bwd(da, qkv, att, lse, dqkv, B, L, H, causal, seq)
-        dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias")
+        dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias", fp8_keys=(pre, "dqkv", "in_w"))
         din = _empty((M, E), torch.float32, x_in)
         din_lp = _empty((M, E), T, x_in) if lp else None
         ops.layernorm_bwd(dh1, x_in, mean1, rstd1, Wf[pre + "ln_1.weight"], Gr[pre + "ln_1.weight"], Gr[pre + "ln_1.bias"],

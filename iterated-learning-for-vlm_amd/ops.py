@@ -66,6 +66,9 @@ class GemmProfiler:
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        f8 = [r for r in self.records if len(r) > 4]
+        fp8 = dict(launches=len(f8), ms=sum(r[0].elapsed_time(r[1]) for r in f8), flops=float(sum(r[2] for r in f8)),
+                   bytes=float(sum(r[3] for r in f8)))
         spans = sorted((self.base.elapsed_time(r[0]), self.base.elapsed_time(r[1])) for r in self.records)
         union, cur_a, cur_b = 0.0, None, None
         for a, b in spans:
@@ -78,7 +81,7 @@ class GemmProfiler:
         if cur_b is not None:
             union += cur_b - cur_a
         return dict(launches=len(self.records), ms=ms, union_ms=union, flops=float(sum(r[2] for r in self.records)),
-                    bytes=float(sum(r[3] for r in self.records)), f32_flops=self.f32_flops)
+                    bytes=float(sum(r[3] for r in self.records)), f32_flops=self.f32_flops, fp8=fp8)
 
 
 _gemm_profiler = None
@@ -172,7 +175,7 @@ def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual
         ev1.record(est)
         nbytes = 1.0 * (m * k + n * k) + m * n * out.element_size() + m * n * (4 if residual is not None else 0) + (
             m * n * 2 if aux is not None else 0)
-        prof.records.append((ev0, ev1, 2.0 * m * n * k, nbytes))
+        prof.records.append((ev0, ev1, 2.0 * m * n * k, nbytes, "fp8"))
     return out
 
 

@@ -66,7 +66,7 @@ class NativeDDP(nn.Module):
         arena = module._eng.arena
         if comm._active(comm.world()[1]):
             distributed.broadcast(arena.P, 0)      # ONE flattened broadcast (reference: one per state_dict tensor)
-        bucket = os.environ.get("ILVLM_GRAD_BUCKET", "bf16" if module._eng.precision == "bf16" else "fp32")
+        bucket = os.environ.get("ILVLM_GRAD_BUCKET", "fp32" if module._eng.precision == "fp32" else "bf16")
         arena.reducer = comm.GradReducer(arena.G, bucket=bucket)
         self._done = []                            # ranges already reduced in this backward
         object.__setattr__(module, "_grad_sync", self._on_sync)
