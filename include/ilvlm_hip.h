@@ -269,6 +269,17 @@ typedef struct ilvlm_block {
     float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b, *g_in_w, *g_in_b, *g_out_w, *g_out_b, *g_fc_w, *g_fc_b, *g_proj_w,
         *g_proj_b;
     int E, H, causal, dtype;
+    /* fp8 mode (BASELINE configs[4]); fp8 = 0 and NULL pointers otherwise.  fp8 = 1: bf16 GEMMs, only the amaxes of the
+     * tensors that would be quantised are recorded (first step: no scale history yet); fp8 = 2: the four forward GEMMs take
+     * e4m3 activations x e4m3 weights and the four input-gradient GEMMs e5m2 gradients x transposed e4m3 weights, weight
+     * gradients stay bf16.  f8_scale / f8_inv / f8_amax: 12 floats each, in the order h1, att, h2, g (GEMM inputs),
+     * in_w, out_w, fc_w, proj_w, d(x_out), du, d(x_mid), dqkv (gradients). */
+    const void *in_w8, *out_w8, *fc_w8, *proj_w8;       /* e4m3, the weights' own [out, in] layout */
+    const void *in_w8t, *out_w8t, *fc_w8t, *proj_w8t;   /* e4m3, transposed [in, out] */
+    const float* f8_scale;
+    const float* f8_inv;
+    float* f8_amax;
+    int fp8;
 } ilvlm_block;
 long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L);
 long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);

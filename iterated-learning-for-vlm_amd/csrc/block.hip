@@ -14,7 +14,7 @@ inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline int esz(int dtype) { return dtype == ILVLM_BF16 ? 2 : 4; }
 
 struct Saved {   // byte offsets into the saved-activation workspace of one block
-    size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, total;
+    size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, q8, total;
     Saved(const ilvlm_block* b, long rows, int B, int L) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
@@ -30,12 +30,13 @@ struct Saved {   // byte offsets into the saved-activation workspace of one bloc
         mean2 = o; o += al(r * 4);
         rstd2 = o; o += al(r * 4);
         lse = o; o += al((size_t)B * b->H * L * 4);
+        q8 = o; if (b->fp8 == 2) o += al(r * 4 * E);     // fp8 copy of the current GEMM input (transient)
         total = o;
     }
 };
 
 struct Scratch {   // backward temporaries
-    size_t du, dh2, dmid, dmid_lp, da, dqkv, dh1, total;
+    size_t du, dh2, dmid, dmid_lp, da, dqkv, dh1, q8, total;
     Scratch(const ilvlm_block* b, long rows) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
@@ -46,6 +47,7 @@ struct Scratch {   // backward temporaries
         da = o; o += al(r * E * es);
         dqkv = o; o += al(r * 3 * E * es);
         dh1 = o; o += al(r * E * es);
+        q8 = o; if (b->fp8 == 2) o += al(r * 4 * E);     // e5m2 copy of the current gradient (transient)
         total = o;
     }
 };
@@ -56,6 +58,10 @@ int check_block(const ilvlm_block* b, const char* who) {
     ILVLM_REQUIRE(b->E > 0 && b->H > 0 && b->E == 64 * b->H, "%s: width %d must be 64 x heads (%d)", who, b->E, b->H);
     ILVLM_REQUIRE(b->ln1_w && b->ln1_b && b->ln2_w && b->ln2_b && b->in_w && b->in_b && b->out_w && b->out_b && b->fc_w &&
                       b->fc_b && b->proj_w && b->proj_b, "%s: null parameter pointer", who);
+    ILVLM_REQUIRE(b->fp8 >= 0 && b->fp8 <= 2, "%s: bad fp8 mode %d", who, b->fp8);
+    ILVLM_REQUIRE(!b->fp8 || b->dtype == ILVLM_BF16, "%s: fp8 mode needs bf16 storage", who);
+    ILVLM_REQUIRE(b->fp8 != 2 || (b->in_w8 && b->out_w8 && b->fc_w8 && b->proj_w8 && b->in_w8t && b->out_w8t && b->fc_w8t &&
+                                  b->proj_w8t && b->E % 128 == 0), "%s: fp8 mode needs the fp8 weights and E %% 128 == 0", who);
     return ILVLM_OK;
 }
 
@@ -75,9 +81,35 @@ int wgrad_split(long out_rows, long out_cols, long k, int tile, int target) {
         if (rc__) return rc__; \
     } while (0)
 
-// dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s
+enum { F8_H1 = 0, F8_ATT, F8_H2, F8_G, F8_IN_W, F8_OUT_W, F8_FC_W, F8_PROJ_W, F8_DOUT, F8_DU, F8_DMID, F8_DQKV };
+
+// fp8 copy of x (n elements) for slot `slot`; fp8 == 1 only records the amax.  Returns the quantised buffer or null.
+int f8_quant(const ilvlm_block* b, const void* x, long n, int slot, int e5m2, void* q8, hipStream_t s, const void** out) {
+    *out = nullptr;
+    if (!b->fp8) return ILVLM_OK;
+    ILVLM_REQUIRE(b->f8_scale && b->f8_inv && b->f8_amax, "block: fp8 mode without scale arrays");
+    if (b->fp8 == 1) return ilvlm_fp8_quantize(x, ILVLM_BF16, nullptr, n, nullptr, b->f8_amax + slot, e5m2, s);
+    int rc = ilvlm_fp8_quantize(x, ILVLM_BF16, q8, n, b->f8_scale + slot, b->f8_amax + slot, e5m2, s);
+    if (rc == ILVLM_OK) *out = q8;
+    return rc;
+}
+
+// forward linear: y = x W^T (+ epilogue); fp8 operands when x8 is given
+int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, const void* W, const void* W8, int slot_w,
+               void* y, long M, int N, int K, ilvlm_gemm_epilogue ep, hipStream_t s) {
+    if (x8) {
+        ep.alpha_ptr = b->f8_inv + slot_a;
+        ep.alpha_ptr2 = b->f8_inv + slot_w;
+        return ilvlm_gemm(ILVLM_FP8, 0, 0, (int)M, N, K, x8, K, W8, K, y, N, &ep, 1, s);
+    }
+    return ilvlm_gemm(b->dtype, 0, 0, (int)M, N, K, x, K, W, K, y, N, &ep, 1, s);
+}
+
+// dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s.
+// dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given.
 int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
-               int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg) {
+               int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
+               const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr) {
     const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
     if (gW || gb) {
         hipStream_t ws = s;
@@ -108,6 +140,11 @@ int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* g
     ep.out_dtype = dtype;
     ep.act = dx_act;
     ep.aux = (void*)dx_aux;
+    if (dy8) {      // dx[m,k] = sum_n dy8[m,n] W8T[k,n]
+        ep.alpha_ptr = inv_g;
+        ep.alpha_ptr2 = inv_w;
+        return ilvlm_gemm(ILVLM_FP8_BF8A, 0, 0, (int)M, K, N, dy8, N, W8T, N, dx, K, &ep, 1, s);
+    }
     return ilvlm_gemm(dtype, 0, 1, (int)M, K, N, dy, N, W, K, dx, K, &ep, 1, s);
 }
 
@@ -134,35 +171,42 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
           *rstd2 = (float*)(w + o.rstd2), *lse = (float*)(w + o.lse), *x_mid = (float*)(w + o.x_mid);
     void *h1 = w + o.h1, *qkv = w + o.qkv, *att = w + o.att, *h2 = w + o.h2, *u = w + o.u, *g = w + o.g;
     // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
+    hipStream_t s = (hipStream_t)stream;
+    void* q8 = w + o.q8;
+    const void* x8;
     TRY(ilvlm_layernorm_fwd(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, stream));
+    TRY(f8_quant(b, h1, rows * E, F8_H1, 0, q8, s, &x8));
     ilvlm_gemm_epilogue ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->in_b;
-    TRY(ilvlm_gemm(T, 0, 0, (int)rows, 3 * E, E, h1, E, b->in_w, E, qkv, 3 * E, &ep, 1, stream));
+    TRY(linear_fwd(b, h1, x8, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
     if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
     else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
+    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, q8, s, &x8));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->out_b;
     ep.residual = x_in;
-    TRY(ilvlm_gemm(T, 0, 0, (int)rows, E, E, att, E, b->out_w, E, x_mid, E, &ep, 1, stream));
+    TRY(linear_fwd(b, att, x8, F8_ATT, b->out_w, b->out_w8, F8_OUT_W, x_mid, rows, E, E, ep, s));
     // x_out = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
     TRY(ilvlm_layernorm_fwd(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, stream));
+    TRY(f8_quant(b, h2, rows * E, F8_H2, 0, q8, s, &x8));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->fc_b;
     ep.aux = u;
     ep.act = ILVLM_ACT_QUICKGELU;
-    TRY(ilvlm_gemm(T, 0, 0, (int)rows, 4 * E, E, h2, E, b->fc_w, E, g, 4 * E, &ep, 1, stream));
+    TRY(linear_fwd(b, h2, x8, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s));
+    TRY(f8_quant(b, g, rows * 4 * E, F8_G, 0, q8, s, &x8));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->proj_b;
     ep.residual = x_mid;
-    return ilvlm_gemm(T, 0, 0, (int)rows, E, 4 * E, g, 4 * E, b->proj_w, 4 * E, x_out, E, &ep, 1, stream);
+    return linear_fwd(b, g, x8, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s);
 }
 
 extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32,
@@ -191,17 +235,29 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     float* ln_ws1 = ln_ws_blocks < 0 ? ln_ws + 2L * (-ln_ws_blocks) * E : ln_ws;
     // MLP
     const void* dy = lp ? dx_lp : (const void*)dx_f32;
-    TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg));
-    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg));
+    void* q8 = t + c.q8;
+    const void* g8;
+    const float* inv = b->f8_inv;
+    // the e5m2 copy is consumed by the input-gradient GEMM on s before the next quantisation (same stream) overwrites it
+    TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, q8, s, &g8));
+    TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
+                   g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W));
+    TRY(f8_quant(b, du, rows * 4 * E, F8_DU, 1, q8, s, &g8));
+    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->fc_w8t,
+                   inv + F8_DU, inv + F8_FC_W));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
     TRY(ilvlm_layernorm_bwd(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
                             b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, s));
     // attention
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
-    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg));
+    TRY(f8_quant(b, dy, rows * E, F8_DMID, 1, q8, s, &g8));
+    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg, g8, b->out_w8t,
+                   inv + F8_DMID, inv + F8_OUT_W));
     if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
     else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
-    TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg));
+    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, q8, s, &g8));
+    TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
+                   inv + F8_DQKV, inv + F8_IN_W));
     return ilvlm_layernorm_bwd(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
                                nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, s);
 }

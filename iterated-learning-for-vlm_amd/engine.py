@@ -292,7 +292,7 @@ class Engine:
         """ilvlm_block descriptor of the transformer block with parameter prefix `pre`, or None when the composite path
         does not apply: switched off (ILVLM_COMPOSITE=0), a GEMM profiler is attached (it times the individual launches),
         or a LayerNorm parameter of the block is frozen."""
-        if not self.composite or ops._gemm_profiler is not None or self.fp8 is not None:
+        if not self.composite or ops._gemm_profiler is not None:
             return None
         d = self._blk.get(pre)
         if d is None:
@@ -306,7 +306,18 @@ class Engine:
                 params = {k: (self.Wc if k in ("in_w", "out_w", "fc_w", "proj_w") else self.Wf)[pre + n] for k, n in names.items()}
                 grads = {"g_" + k: (self.Gr[pre + n] if self.req[pre + n] else None) for k, n in names.items()}
                 d = ops.block_desc(E, H, causal, self.T, params, grads)
+                if self.fp8 is not None:
+                    f8 = self.fp8
+                    base = f8.slots[pre + "h1"]
+                    for k in f8.WEIGHT:
+                        setattr(d, k + "8", f8.w8(pre, k).data_ptr())
+                        setattr(d, k + "8t", f8.w8(pre, k, transposed=True).data_ptr())
+                    d.f8_scale = f8.scale[base:].data_ptr()
+                    d.f8_inv = f8.inv[base:].data_ptr()
+                    d.f8_amax = f8.amax[base:].data_ptr()
             self._blk[pre] = d
+        if d and self.fp8 is not None:
+            d.fp8 = 2 if self.fp8.active else 1
         return d or None
 
     def _mat(self, name):

@@ -25,7 +25,9 @@ class Block(C.Structure):
     _fields_ = ([(n, vp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "in_w", "out_w", "fc_w", "proj_w", "in_b", "out_b",
                                    "fc_b", "proj_b", "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_in_w", "g_in_b", "g_out_w",
                                    "g_out_b", "g_fc_w", "g_fc_b", "g_proj_w", "g_proj_b")] +
-                [("E", i32), ("H", i32), ("causal", i32), ("dtype", i32)])
+                [("E", i32), ("H", i32), ("causal", i32), ("dtype", i32)] +
+                [(n, vp) for n in ("in_w8", "out_w8", "fc_w8", "proj_w8", "in_w8t", "out_w8t", "fc_w8t", "proj_w8t", "f8_scale",
+                                   "f8_inv", "f8_amax")] + [("fp8", i32)])
 
 
 class AdamWHyper(C.Structure):
