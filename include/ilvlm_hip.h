@@ -10,8 +10,10 @@
  *    caching allocator); the library never allocates, frees or retains device memory.
  *  - every function returns 0 on success, ILVLM_ERR_ARG (<0) for a rejected argument or a positive
  *    hipError_t; the message is in the thread-local ilvlm_last_error().  No exceptions, no exit().
- *  - launches are asynchronous on `stream` (a hipStream_t passed as void*); re-entrant, no global
- *    mutable state (forward runs on the main thread, backward on autograd's worker thread).
+ *  - launches are asynchronous on `stream` (a hipStream_t passed as void*); re-entrant (forward runs on
+ *    the main thread, backward on autograd's worker thread).  The only process-wide mutable state is the
+ *    kernel-selection knob of ilvlm_gemm_set_variant (one atomic int, a tuning / test hook) and the
+ *    once-only hipFuncSetAttribute of each kernel (std::call_once).
  *  - dtype arguments: ILVLM_F32 or ILVLM_BF16.  "T" below means "the dtype argument of that call".
  *  - all matrices are row-major with the row stride given where it can differ from the width.
  *  - gradient outputs documented as "+=" are ACCUMULATED (fp32 atomics) into zero-initialised or
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ILVLM_VERSION 100 /* round 1 */
+#define ILVLM_VERSION 200 /* round 2 */
 
 enum { ILVLM_OK = 0, ILVLM_ERR_ARG = -1 };
 enum { ILVLM_F32 = 0, ILVLM_BF16 = 1,
@@ -93,9 +95,10 @@ typedef struct ilvlm_gemm_epilogue {
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
-/* bf16 kernel selection (tuning / tests): 0 register-staged general kernel, 5 direct-to-LDS 128x128 (default),
- * 6 direct-to-LDS 64x128 (K-contiguous A operand), 7 direct-to-LDS 256x128 with a 3-stage ring.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
- * K-strided operands) always use the general kernel. */
+/* bf16 kernel selection (tuning / tests; process-wide atomic): 0 register-staged general kernel, 5 direct-to-LDS 128x128
+ * (default), 6 direct-to-LDS 64x128 (K-contiguous A operand), 7 direct-to-LDS 256x128 with a 3-stage ring, 8 the 256x256
+ * phased 8-wave kernel (one workgroup per CU), 9 direct-to-LDS 256x128 single stage.  Shapes the direct-to-LDS kernels
+ * cannot take (K % 64 != 0, ragged K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-5 affine; base_transformer.py:10-18, clip_fdt.py:86-92) ----

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), "libilvlm_hip.so does not export %s" % n
     # and the ctypes table binds every one of them (except the two argument-less queries)
     assert set(names) - {"ilvlm_version", "ilvlm_last_error"} == set(lib.SIGNATURES)
-    assert handle.ilvlm_version() == 100
+    assert handle.ilvlm_version() == 200
 
 
 def test_bad_arguments_are_rejected_without_a_launch():
