@@ -91,6 +91,13 @@ typedef struct ilvlm_gemm_epilogue {
     const int32_t* pool_offs;
     int pool_group;
     const float* alpha_ptr2; /* second device scalar multiplied into alpha (fp8: the two de-quantisation scales) or NULL */
+    /* fp8 copy of the stored output for the next fp8 GEMM (fp8 mode): out8[m, n] (bytes, same ldc) = fp8(value * out8_scale[0])
+     * in e4m3 (out8_fmt 0) or e5m2 (1); out8_amax[0] is raised to max|value| (either may be NULL).  Direct-to-LDS bf16 /
+     * fp8 kernels only, not with accumulate or the pool epilogue, out_group == 0. */
+    void* out8;
+    const float* out8_scale;
+    float* out8_amax;
+    int out8_fmt;
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
@@ -107,6 +114,11 @@ int ilvlm_gemm_set_variant(int variant);
 int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                         float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
                         void* stream);
+/* the same, additionally emitting an OCP e4m3 copy y8 = fp8(y * q_scale[0]) of the output (the next GEMM's fp8 operand) and
+ * raising q_amax[0] to max|y| (either may be NULL); compact rows only (fp8 mode, BASELINE configs[4]) */
+int ilvlm_layernorm_fwd_q8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                           float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip, void* y8,
+                           const float* q_scale, float* q_amax, void* stream);
 /* dx = LN'(dy) [+ dres]; writes dx_f32 (fp32) and/or dx_lp (dtype dx_lp_dtype, optionally multiplied by
  * act'(act_aux) for act in {ILVLM_ACT_QUICKGELU_BWD, ILVLM_ACT_GELU_ERF_BWD}); dgamma/dbeta "+=".
  * x, dres, dx_f32, dx_lp use the remapped rows when group > 0; dy, mean, rstd, act_aux are compact. */
@@ -119,6 +131,12 @@ int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype
  * n_slots such launches (slot z at ws + z * slot_stride, same rows / |ws_blocks| / cols for all) into grad_ptrs[2z]
  * (dgamma) and grad_ptrs[2z+1] (dbeta), a DEVICE array of 2 * n_slots pointers -- one launch per tower instead of one
  * per LayerNorm (50 per step). */
+/* ilvlm_layernorm_bwd that also emits an OCP e5m2 copy dx8 = fp8(dx_lp * q_scale[0]) of the low-precision gradient and
+ * raises q_amax[0] to max|dx_lp| (either may be NULL); compact rows only */
+int ilvlm_layernorm_bwd_q8(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                           const float* gamma, const float* dres, float* dx_f32, void* dx_lp, int dx_lp_dtype, int act,
+                           const void* act_aux, float* dgamma, float* dbeta, long rows, int cols, int group, int skip, float* ws,
+                           int ws_blocks, void* dx8, const float* q_scale, float* q_amax, void* stream);
 int ilvlm_layernorm_bwd_reduce_batched(const float* ws, long slot_stride, int n_slots, long rows, int ws_blocks, int cols,
                                        float* const* grad_ptrs, void* stream);
 /* ws: optional workspace of 2 * ws_blocks * cols floats: per-workgroup dgamma/dbeta partials are written there and
@@ -295,7 +313,11 @@ int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x_out, void*
  * chip). */
 int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32, const void* dx_lp,
                     float* din_f32, void* din_lp, void* scratch, float* ln_ws, int ln_ws_blocks, long rows, int B, int L,
-                    int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream);
+                    int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream, const void* dx8,
+                    void* din8, const float* din8_scale, float* din8_amax);
+/* fp8 mode (b->fp8 == 2), all four nullable: dx8 = e5m2 copy of dx_lp if the producer already made one (the previous call's
+ * din8), else the call quantises dx_lp itself; din8 [rows, E] bytes receives the e5m2 copy of din_lp, quantised with
+ * din8_scale[0] (the d(x_out) slot of the block that will consume it), din8_amax[0] raised to max|din_lp|. */
 
 /* ---- packed text rows.  Positions behind <|endoftext|> never reach the loss: attention is causal
  * (text_transformer.py:147-153), the FDT scores of masked tokens are multiplied by zero (clip_fdt.py:118-123) and the

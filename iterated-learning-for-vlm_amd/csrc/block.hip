@@ -30,7 +30,7 @@ struct Saved {   // byte offsets into the saved-activation workspace of one bloc
         mean2 = o; o += al(r * 4);
         rstd2 = o; o += al(r * 4);
         lse = o; o += al((size_t)B * b->H * L * 4);
-        q8 = o; if (b->fp8 == 2) o += al(r * 4 * E);     // fp8 copy of the current GEMM input (transient)
+        q8 = o; if (b->fp8 == 2) o += al(r * E) + al(r * 4 * E);   // fp8 copies: E-wide GEMM input, 4E-wide MLP activation
         total = o;
     }
 };
@@ -47,7 +47,7 @@ struct Scratch {   // backward temporaries
         da = o; o += al(r * E * es);
         dqkv = o; o += al(r * 3 * E * es);
         dh1 = o; o += al(r * E * es);
-        q8 = o; if (b->fp8 == 2) o += al(r * 4 * E);     // e5m2 copy of the current gradient (transient)
+        q8 = o; if (b->fp8 == 2) o += al(r * E) + al(r * 4 * E);   // e5m2 copies: E-wide gradient, up to 4E-wide gradient
         total = o;
     }
 };
@@ -109,7 +109,8 @@ int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, 
 // dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given.
 int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
                int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
-               const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr) {
+               const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr, void* dx8 = nullptr,
+               const float* dx8_scale = nullptr, float* dx8_amax = nullptr) {
     const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
     if (gW || gb) {
         hipStream_t ws = s;
@@ -140,6 +141,10 @@ int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* g
     ep.out_dtype = dtype;
     ep.act = dx_act;
     ep.aux = (void*)dx_aux;
+    ep.out8 = dx8;                  // e5m2 copy (and amax) of dx for the next input-gradient GEMM
+    ep.out8_scale = dx8_scale;
+    ep.out8_amax = dx8_amax;
+    ep.out8_fmt = 1;
     if (dy8) {      // dx[m,k] = sum_n dy8[m,n] W8T[k,n]
         ep.alpha_ptr = inv_g;
         ep.alpha_ptr2 = inv_w;
@@ -171,19 +176,25 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
           *rstd2 = (float*)(w + o.rstd2), *lse = (float*)(w + o.lse), *x_mid = (float*)(w + o.x_mid);
     void *h1 = w + o.h1, *qkv = w + o.qkv, *att = w + o.att, *h2 = w + o.h2, *u = w + o.u, *g = w + o.g;
     // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
+    // fp8 mode: the fp8 copy of each GEMM input is emitted by its producer where that is a kernel of this library with the
+    // values in registers (LayerNorm, the fc GEMM's QuickGELU epilogue); the attention output takes a quantise pass
     hipStream_t s = (hipStream_t)stream;
-    void* q8 = w + o.q8;
+    const bool f8on = b->fp8 == 2, f8obs = b->fp8 != 0;
+    void* q8a = w + o.q8;                           // [rows, E] bytes
+    void* q8g = w + o.q8 + al((size_t)rows * E);    // [rows, 4E] bytes
+    const float* sc = b->f8_scale;
+    float* am = b->f8_amax;
     const void* x8;
-    TRY(ilvlm_layernorm_fwd(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, stream));
-    TRY(f8_quant(b, h1, rows * E, F8_H1, 0, q8, s, &x8));
+    TRY(ilvlm_layernorm_fwd_q8(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, f8on ? q8a : nullptr,
+                               f8on ? sc + F8_H1 : nullptr, f8obs ? am + F8_H1 : nullptr, stream));
     ilvlm_gemm_epilogue ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->in_b;
-    TRY(linear_fwd(b, h1, x8, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
+    TRY(linear_fwd(b, h1, f8on ? q8a : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
     if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
     else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
-    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, q8, s, &x8));
+    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, q8a, s, &x8));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
@@ -191,28 +202,34 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.residual = x_in;
     TRY(linear_fwd(b, att, x8, F8_ATT, b->out_w, b->out_w8, F8_OUT_W, x_mid, rows, E, E, ep, s));
     // x_out = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
-    TRY(ilvlm_layernorm_fwd(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, stream));
-    TRY(f8_quant(b, h2, rows * E, F8_H2, 0, q8, s, &x8));
+    TRY(ilvlm_layernorm_fwd_q8(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, f8on ? q8a : nullptr,
+                               f8on ? sc + F8_H2 : nullptr, f8obs ? am + F8_H2 : nullptr, stream));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->fc_b;
     ep.aux = u;
     ep.act = ILVLM_ACT_QUICKGELU;
-    TRY(linear_fwd(b, h2, x8, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s));
-    TRY(f8_quant(b, g, rows * 4 * E, F8_G, 0, q8, s, &x8));
+    if (f8obs) {                                    // the activation's fp8 copy (and amax) straight from the epilogue
+        ep.out8 = f8on ? q8g : nullptr;
+        ep.out8_scale = f8on ? sc + F8_G : nullptr;
+        ep.out8_amax = am + F8_G;
+        ep.out8_fmt = 0;
+    }
+    TRY(linear_fwd(b, h2, f8on ? q8a : nullptr, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->proj_b;
     ep.residual = x_mid;
-    return linear_fwd(b, g, x8, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s);
+    return linear_fwd(b, g, f8on ? q8g : nullptr, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s);
 }
 
 extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32,
                                const void* dx_lp, float* din_f32, void* din_lp, void* scratch, float* ln_ws,
                                int ln_ws_blocks, long rows, int B, int L, int Lcap, const int32_t* seq_offs,
-                               int wgrad_target, void* stream, void* wgrad_stream) {
+                               int wgrad_target, void* stream, void* wgrad_stream, const void* dx8, void* din8,
+                               const float* din8_scale, float* din8_amax) {
     TRY(check_block(b, "block_bwd"));
     ILVLM_REQUIRE(x_in && saved && dx_f32 && din_f32 && scratch && rows > 0 && B > 0 && L > 0, "block_bwd: bad arguments");
     const int E = b->E, T = b->dtype;
@@ -235,29 +252,39 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     float* ln_ws1 = ln_ws_blocks < 0 ? ln_ws + 2L * (-ln_ws_blocks) * E : ln_ws;
     // MLP
     const void* dy = lp ? dx_lp : (const void*)dx_f32;
-    void* q8 = t + c.q8;
-    const void* g8;
+    // fp8 mode: e5m2 copies of the gradients entering the four input-gradient GEMMs.  d(x_out) arrives from the caller when
+    // the previous call (the next block) emitted it (din8); du comes out of the proj input-gradient GEMM's epilogue, d(x_mid)
+    // out of ln_2's backward, dqkv takes a quantise pass; ln_1's backward emits the next call's d(x_out) into din8.
+    const bool f8on = b->fp8 == 2, f8obs = b->fp8 != 0;
+    void* q8e = t + c.q8;                             // [rows, E]
+    void* q8w = t + c.q8 + al((size_t)rows * E);      // [rows, <= 4E]
+    const float* sc = b->f8_scale;
     const float* inv = b->f8_inv;
-    // the e5m2 copy is consumed by the input-gradient GEMM on s before the next quantisation (same stream) overwrites it
-    TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, q8, s, &g8));
+    float* am = b->f8_amax;
+    const void* g8 = nullptr;
+    ILVLM_REQUIRE(!(dx8 || din8) || f8on, "block_bwd: fp8 gradient copies only in active fp8 mode");
+    ILVLM_REQUIRE(!din8 || din8_scale, "block_bwd: din8 needs its scale");
+    if (dx8) g8 = dx8;
+    else TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, q8e, s, &g8));
+    // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
-                   g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W));
-    TRY(f8_quant(b, du, rows * 4 * E, F8_DU, 1, q8, s, &g8));
-    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->fc_w8t,
-                   inv + F8_DU, inv + F8_FC_W));
+                   g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? q8w : nullptr, f8on ? sc + F8_DU : nullptr,
+                   f8obs ? am + F8_DU : nullptr));
+    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
+                   f8on ? q8w : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
-    TRY(ilvlm_layernorm_bwd(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
-                            b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, s));
+    TRY(ilvlm_layernorm_bwd_q8(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
+                               b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, f8on ? q8e : nullptr, f8on ? sc + F8_DMID : nullptr,
+                               f8obs ? am + F8_DMID : nullptr, s));
     // attention
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
-    TRY(f8_quant(b, dy, rows * E, F8_DMID, 1, q8, s, &g8));
-    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg, g8, b->out_w8t,
-                   inv + F8_DMID, inv + F8_OUT_W));
+    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
+                   f8on ? q8e : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W));
     if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
     else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
-    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, q8, s, &g8));
+    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, q8w, s, &g8));
     TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
                    inv + F8_DQKV, inv + F8_IN_W));
-    return ilvlm_layernorm_bwd(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
-                               nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, s);
+    return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
+                                  nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, din8, din8_scale, din8_amax, s);
 }

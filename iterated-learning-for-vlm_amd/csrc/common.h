@@ -118,3 +118,30 @@ __host__ __device__ __forceinline__ long map_row(long r, int group, int skip) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- fp8 (OCP) helpers shared by fp8.hip and the kernels that emit an fp8 copy of their output ------------------
+// FMT 0 = e4m3 (max 448), 1 = e5m2 (max 57344); saturating
+template <int FMT>
+__device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d) {
+    const float mx = FMT == 0 ? 448.f : 57344.f;
+    a = fminf(fmaxf(a, -mx), mx); b = fminf(fmaxf(b, -mx), mx);
+    c = fminf(fmaxf(c, -mx), mx); d = fminf(fmaxf(d, -mx), mx);
+    int w = 0;
+    if (FMT == 0) {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    }
+    return (unsigned)w;
+}
+__device__ __forceinline__ unsigned fp8_pack4_fmt(int fmt, float a, float b, float c, float d) {
+    return fmt == 0 ? fp8_pack4<0>(a, b, c, d) : fp8_pack4<1>(a, b, c, d);
+}
+// raise *amax to m (m >= 0).  Thousands of waves raising ONE word serialise at ~12 ns per atomic, so only a wave that would
+// actually raise the maximum issues one (the plain read may be stale; the atomic max keeps the result exact).
+__device__ __forceinline__ void fp8_amax_raise(float* amax, float m) {
+    if (m > 0.f && m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax((unsigned*)amax, __float_as_uint(m));
+}

@@ -24,8 +24,22 @@ struct EpiArgs {
 };
 
 // Handles 4 consecutive columns [n, n+4) of output row m.  AuxT = compute dtype.
+// fp8 copy of 4 stored values (or fewer at a ragged edge) + running max|value| for the amax
+__device__ __forceinline__ void out8_store(const ilvlm_gemm_epilogue& e, long off, f32x4 v, int nvalid, float& amax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nvalid) amax = fmaxf(amax, fabsf(v[i]));
+    if (!e.out8) return;
+    const float s = e.out8_scale ? e.out8_scale[0] : 1.f;
+    const unsigned w = fp8_pack4_fmt(e.out8_fmt, v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    unsigned char* p = (unsigned char*)e.out8 + off;
+    if (nvalid == 4 && (off & 3) == 0) *(unsigned*)p = w;
+    else
+        for (int i = 0; i < nvalid; ++i) p[i] = (unsigned char)(w >> (8 * i));
+}
+
 template <class AuxT>
-__device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 v, float alpha) {
+__device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 v, float alpha, float* amax8 = nullptr) {
     if (m >= a.M || n >= a.N) return;
     const ilvlm_gemm_epilogue& e = a.e;
     long orow = map_row(m, e.out_group, e.out_skip);
@@ -57,8 +71,10 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
         if (e.residual) v += *(const f32x4*)(e.residual + off);
         if (e.out_dtype == ILVLM_F32) store4<float>(a.Cf + off, v);
         else store4<bf16>(a.Cb + off, v);
+        if (amax8) out8_store(e, off, v, 4, *amax8);
         return;
     }
+    f32x4 fin = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (n + i >= a.N) break;
@@ -75,7 +91,9 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
         if (e.residual) x += e.residual[off + i];
         if (e.out_dtype == ILVLM_F32) a.Cf[off + i] = x;
         else a.Cb[off + i] = (bf16)x;
+        fin[i] = x;
     }
+    if (amax8) out8_store(e, off, fin, min(4, a.N - n), *amax8);
 }
 
 // XCD-aware bijective remap (blocks b and b+8 share an XCD; give each XCD a contiguous tile range)
@@ -408,7 +426,7 @@ enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, 
 // array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
 template <int MODE, int TI, int TJ, int P>
 __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n, int lane, float alpha,
-                                              unsigned char* wlds, f32x4 bias) {
+                                              unsigned char* wlds, f32x4 bias, float& amax8) {
     if constexpr (P < TI / 2) {
         const ilvlm_gemm_epilogue& e = ep.e;
         const int g = lane >> 4, c = lane & 15;
@@ -456,7 +474,7 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
             for (int hk = 0; hk < 8; ++hk) {
                 const int row = 4 * hk + g;
                 const f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
-                epilogue4<bf16>(ep, m_base + P * 32 + row, n, v, alpha);
+                epilogue4<bf16>(ep, m_base + P * 32 + row, n, v, alpha, (e.out8 || e.out8_amax) ? &amax8 : nullptr);
             }
         } else {
 #pragma unroll 1
@@ -488,12 +506,13 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
                     if constexpr (MODE == EPI_RES) v += pre[k];
                     if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
                     else store4<bf16>(ep.Cb + off[k], v);
+                    if (e.out8 || e.out8_amax) out8_store(e, off[k], v, 4, amax8);
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
-        epilogue_pass<MODE, TI, TJ, P + 1>(ep, acc, m_base, n, lane, alpha, wlds, bias);
+        epilogue_pass<MODE, TI, TJ, P + 1>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
     }
 }
 
@@ -511,15 +530,20 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
     }
     const int n = n_base + 4 * (lane & 15);          // this lane's columns after the transpose
     const f32x4 bias = (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
+    float amax8 = 0.f;
     switch (mode) {
-        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
-        default: epilogue_pass<EPI_GENERIC, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias); break;
+        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        default: epilogue_pass<EPI_GENERIC, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+    }
+    if (e.out8_amax) {          // one conditional atomic per wave and tile
+        amax8 = wave_max(amax8);
+        if (lane == 0) fp8_amax_raise(e.out8_amax, amax8);
     }
 }
 
@@ -1170,6 +1194,9 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ILVLM_REQUIRE(!(epi->accumulate && epi->out_dtype != ILVLM_F32), "gemm: accumulate needs fp32 output");
     ILVLM_REQUIRE(!(compute_dtype == ILVLM_F32 && epi->out_dtype != ILVLM_F32), "gemm: fp32 compute writes fp32");
     const bool fp8 = compute_dtype == ILVLM_FP8 || compute_dtype == ILVLM_FP8_BF8A;
+    ILVLM_REQUIRE(!(epi->out8 || epi->out8_amax) || ((fp8 || compute_dtype == ILVLM_BF16) && !epi->accumulate && !epi->pool_out &&
+                                                     epi->out_group == 0 && (epi->out8_fmt == 0 || epi->out8_fmt == 1)),
+                  "gemm: the fp8 output copy needs bf16 / fp8 compute, no accumulate / pool epilogue, compact rows");
     ILVLM_REQUIRE(!fp8 || (!trans_a && !trans_b && !epi->accumulate && !epi->a_rowsum && !epi->pool_out && K % 128 == 0 &&
                            lda % 16 == 0 && ldb % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0),
                   "gemm fp8: K-contiguous operands only (trans_a = trans_b = 0), no accumulate, K %% 128 == 0, 16-byte aligned rows");
@@ -1257,6 +1284,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         }
         ILVLM_REQUIRE(epi->a_rowsum == nullptr, "gemm: a_rowsum needs the direct-to-LDS path (K %% 64 == 0, M %% 8 == 0)");
         ILVLM_REQUIRE(epi->pool_out == nullptr, "gemm: the pool epilogue needs the direct-to-LDS path (K %% 64 == 0)");
+        ILVLM_REQUIRE(!epi->out8 && !epi->out8_amax, "gemm: the fp8 output copy needs the direct-to-LDS path (K %% 64 == 0)");
 #define ILVLM_DISPATCH(TA, TB)                                                                       \
     return swap ? launch_bf16<TA, TB, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)               \
                 : launch_bf16<TA, TB, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s)

@@ -13,10 +13,13 @@ template <class TX, class TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows, int cols,
-                                                     float eps, int group, int skip) {
+                                                     float eps, int group, int skip, unsigned char* __restrict__ y8,
+                                                     const float* __restrict__ q_scale, float* __restrict__ q_amax) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= rows) return;
+    const float qs = (y8 && q_scale) ? q_scale[0] : 1.f;       // fp8 (e4m3) copy of the output for the fp8 GEMMs
+    float qm = 0.f;
     const TX* xr = x + map_row(row, group, skip) * (long)cols;
     f32x4 v[MAXV];
     float s = 0.f;
@@ -49,7 +52,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
             store4<TY>(yr + c, o);
+            if (q_amax) qm = fmaxf(qm, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            if (y8) *(unsigned*)(y8 + row * (long)cols + c) = fp8_pack4<0>(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
         }
+    }
+    if (q_amax) {
+        qm = wave_max(qm);
+        if (lane == 0) fp8_amax_raise(q_amax, qm);
     }
 }
 
@@ -61,9 +70,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      float* __restrict__ dx_f32, TLP* __restrict__ dx_lp, int act,
                                                      const TLP* __restrict__ act_aux, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, long rows, int cols, int group, int skip,
-                                                     float* __restrict__ ws) {
+                                                     float* __restrict__ ws, unsigned char* __restrict__ dx8,
+                                                     const float* __restrict__ q_scale, float* __restrict__ q_amax) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float qs = (dx8 && q_scale) ? q_scale[0] : 1.f;      // fp8 (e5m2) copy of the low-precision gradient
+    float qm = 0.f;
     f32x4 ag[NV], ab[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = (f32x4){0, 0, 0, 0}; }
@@ -117,9 +129,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                             o[j] *= act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
                     }
                     store4<TLP>(dx_lp + srow * (long)cols + c, o);
+                    if (q_amax) qm = fmaxf(qm, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                    if (dx8) *(unsigned*)(dx8 + srow * (long)cols + c) = fp8_pack4<1>(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
                 }
             }
         }
+    }
+    if (q_amax) {
+        qm = wave_max(qm);
+        if (lane == 0) fp8_amax_raise(q_amax, qm);
     }
     // workgroup reduction of the per-wave column partials, then one atomic per column
 #pragma unroll
@@ -209,9 +227,19 @@ extern "C" int ilvlm_layernorm_bwd_reduce_batched(const float* ws, long slot_str
     return ILVLM_OK;
 }
 
+extern "C" int ilvlm_layernorm_fwd_q8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                      float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
+                                      void* y8, const float* q_scale, float* q_amax, void* stream);
 extern "C" int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                                    float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
                                    void* stream) {
+    return ilvlm_layernorm_fwd_q8(x, x_dtype, gamma, beta, y, y_dtype, mean, rstd, rows, cols, eps, in_group, in_skip, nullptr,
+                                  nullptr, nullptr, stream);
+}
+extern "C" int ilvlm_layernorm_fwd_q8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                      float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
+                                      void* y8, const float* q_scale, float* q_amax, void* stream) {
+    ILVLM_REQUIRE(!y8 || (q_scale && in_group == 0), "layernorm_fwd_q8: the fp8 copy needs a scale and compact rows");
     ILVLM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     ILVLM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXV * 256, "layernorm_fwd: cols=%d must be a multiple of 4 and <= %d",
                   cols, MAXV * 256);
@@ -219,7 +247,7 @@ extern "C" int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamm
     dim3 grid(ceil_div(rows, 4)), block(256);
 #define LN_FWD(TX, TY)                                                                                               \
     hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, \
-                       cols, eps, in_group, in_skip)
+                       cols, eps, in_group, in_skip, (unsigned char*)y8, q_scale, q_amax)
     if (x_dtype == ILVLM_F32 && y_dtype == ILVLM_F32) LN_FWD(float, float);
     else if (x_dtype == ILVLM_F32 && y_dtype == ILVLM_BF16) LN_FWD(float, bf16);
     else if (x_dtype == ILVLM_BF16 && y_dtype == ILVLM_BF16) LN_FWD(bf16, bf16);
@@ -230,10 +258,25 @@ extern "C" int ilvlm_layernorm_fwd(const void* x, int x_dtype, const float* gamm
     return ILVLM_OK;
 }
 
+extern "C" int ilvlm_layernorm_bwd_q8(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                      const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
+                                      int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
+                                      int cols, int group, int skip, float* ws, int ws_blocks, void* dx8, const float* q_scale,
+                                      float* q_amax, void* stream);
 extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                                    const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
                                    int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
                                    int cols, int group, int skip, float* ws, int ws_blocks, void* stream) {
+    return ilvlm_layernorm_bwd_q8(dy, dy_dtype, x, x_dtype, mean, rstd, gamma, dres, dx_f32, dx_lp, dx_lp_dtype, act, act_aux, dgamma,
+                                  dbeta, rows, cols, group, skip, ws, ws_blocks, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int ilvlm_layernorm_bwd_q8(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                      const float* rstd, const float* gamma, const float* dres, float* dx_f32, void* dx_lp,
+                                      int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
+                                      int cols, int group, int skip, float* ws, int ws_blocks, void* dx8, const float* q_scale,
+                                      float* q_amax, void* stream) {
+    ILVLM_REQUIRE(!(dx8 || q_amax) || (dx_lp && group == 0 && (!dx8 || q_scale)),
+                  "layernorm_bwd_q8: the fp8 copy follows the low-precision gradient (dx_lp), compact rows, with a scale");
     ILVLM_REQUIRE(dy && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
     ILVLM_REQUIRE(dx_f32 || dx_lp, "layernorm_bwd: no output requested");
     ILVLM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXV * 256, "layernorm_bwd: bad cols %d", cols);
@@ -252,7 +295,8 @@ extern "C" int ilvlm_layernorm_bwd(const void* dy, int dy_dtype, const void* x, 
     const int nv = (cols + 255) / 256;   // register slots actually needed (1..4): fewer VGPRs -> more waves per SIMD
 #define LN_BWD_NV(TDY, TX, TLP, NV)                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NV>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean, rstd,    \
-                       gamma, dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip, ws)
+                       gamma, dres, dx_f32, (TLP*)dx_lp, act, (const TLP*)act_aux, dgamma, dbeta, rows, cols, group, skip, ws, \
+                       (unsigned char*)dx8, q_scale, q_amax)
 #define LN_BWD(TDY, TX, TLP)                                                                                          \
     do {                                                                                                              \
         if (nv == 1) LN_BWD_NV(TDY, TX, TLP, 1);                                                                      \

@@ -217,6 +217,7 @@ class Engine:
         self.fused_fdt = os.environ.get("ILVLM_FUSED_FDT", "1") == "1"    # codebook scores + token max-pool in one GEMM
         self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
         self.defer_ln = os.environ.get("ILVLM_DEFER_LN", "1") == "1"      # one LayerNorm-gradient reduction per tower
+        self._f8_carry = None
         self._ln_defer = {}
         self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
@@ -432,7 +433,7 @@ class Engine:
         slots, ptrs = st
         ops.ln_reduce_batched(slots, slots.shape[2], slots.shape[0] * 2, rows, E, ptrs)
 
-    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None, ln_slots=None):
+    def block_bwd(self, saved, pre, dx_f32, dx_lp, B, L, H, causal, seq=None, ln_slots=None, f8_in=None, f8_next=None):
         """dx_f32: fp32 gradient of the block output; dx_lp: the same in T (None in fp32 mode).  Returns the pair
         for the block input.  ln_slots: this block's two deferred LayerNorm slots (composite path only)."""
         if len(saved) == 2:       # saved by the composite forward: composite backward (ilvlm_block_bwd)
@@ -447,7 +448,16 @@ class Engine:
             if wg is not None:    # the scratch holds the dY operands of the weight-gradient GEMMs: alive until the join
                 self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(scratch)
                 self._wg_keep[torch.cuda.current_stream().cuda_stream].append(dx_lp if lp else dx_f32)
-            ops.block_bwd(desc, x_in, ws, dx_f32, dx_lp, din, din_lp, scratch, B, L, seq, wg, ln_slots)
+            # fp8 mode: f8_in = e5m2 copy of dx_lp made by the block processed before this one; f8_next = prefix of the block
+            # that consumes this call's input gradient (its d(x_out) slot scales the copy this call emits)
+            din8 = sc8 = am8 = None
+            if self.fp8 is not None and self.fp8.active and f8_next is not None:
+                din8 = torch.empty((M, E), dtype=torch.uint8, device=x_in.device)
+                sc8, _, am8 = self.fp8.s(f8_next + "dout")
+            ops.block_bwd(desc, x_in, ws, dx_f32, dx_lp, din, din_lp, scratch, B, L, seq, wg, ln_slots,
+                          dx8=f8_in if (self.fp8 is not None and self.fp8.active) else None, din8=din8, din8_scale=sc8,
+                          din8_amax=am8)
+            self._f8_carry = din8
             return din, din_lp
         x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
         M, E = x_in.shape
@@ -514,9 +524,13 @@ class Engine:
         composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
         st = self._ln_defer_begin("v", cfg["v_layers"], W) if composite and all(
             self.req["visual.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["v_layers"])) else None
+        carry = None
         for i in reversed(range(cfg["v_layers"])):
+            self._f8_carry = None
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "visual.transformer.resblocks.%d." % i, dx_f32, dx_lp, B, Lv,
-                                           cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None)
+                                           cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None, f8_in=carry,
+                                           f8_next=("visual.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
+            carry = self._f8_carry
             if self.arena.reducer is not None:
                 self.join_wgrad()
             self.m._sync("visual.transformer.resblocks.%d." % i)       # this block's gradients are complete
@@ -593,9 +607,14 @@ class Engine:
         composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
         st = self._ln_defer_begin("t", cfg["t_layers"], saved["Wt"]) if composite and all(
             self.req["encode_text.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["t_layers"])) else None
+        carry = None
         for i in reversed(range(cfg["t_layers"])):
+            self._f8_carry = None
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
-                                           Lt, cfg["t_heads"], 1, saved["seq"], ln_slots=st[0][i] if st is not None else None)
+                                           Lt, cfg["t_heads"], 1, saved["seq"], ln_slots=st[0][i] if st is not None else None,
+                                           f8_in=carry,
+                                           f8_next=("encode_text.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
+            carry = self._f8_carry
             if self.arena.reducer is not None:
                 self.join_wgrad()
             self.m._sync("encode_text.transformer.resblocks.%d." % i)

@@ -17,7 +17,8 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("rowbias", vp), ("residual", vp), ("aux", vp), ("alpha_ptr", vp),
                 ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
                 ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp),
-                ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32), ("alpha_ptr2", vp)]
+                ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32), ("alpha_ptr2", vp),
+                ("out8", vp), ("out8_scale", vp), ("out8_amax", vp), ("out8_fmt", i32)]
 
 
 class Block(C.Structure):
@@ -41,6 +42,8 @@ SIGNATURES = {
     "ilvlm_gemm_set_variant": [i32],
     "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
     "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp],
+    "ilvlm_layernorm_fwd_q8": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp, vp],
+    "ilvlm_layernorm_bwd_q8": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp],
     "ilvlm_layernorm_bwd_reduce_batched": [vp, i64, i32, i64, i32, i32, vp, vp],
     "ilvlm_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ilvlm_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -80,7 +83,7 @@ SIGNATURES = {
     "ilvlm_block_saved_bytes": [C.POINTER(Block), i64, i32, i32],
     "ilvlm_block_scratch_bytes": [C.POINTER(Block), i64],
     "ilvlm_block_fwd": [C.POINTER(Block), vp, vp, vp, i64, i32, i32, i32, vp, vp],
-    "ilvlm_block_bwd": [C.POINTER(Block), vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp],
+    "ilvlm_block_bwd": [C.POINTER(Block), vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp],
     "ilvlm_embed_packed_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_embed_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_attention_packed_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],

@@ -287,7 +287,8 @@ def ln_reduce_batched(ws, slot_stride, n_slots, rows, cols, grad_ptrs):
                                                         grad_ptrs.data_ptr(), _stream()), "layernorm_bwd_reduce_batched")
 
 
-def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq, seq=None, wgrad_stream=None, ln_slots=None):
+def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq, seq=None, wgrad_stream=None, ln_slots=None,
+              dx8=None, din8=None, din8_scale=None, din8_amax=None):
     """ln_slots: fp32 tensor of 2 slots x 2 * LN_WS_BLOCKS * E floats -> the LayerNorm dgamma / dbeta second stages are
     deferred (ln_2's partials in slot 0, ln_1's in slot 1; ln_reduce_batched adds them up); None: reduced immediately."""
     rows = x_in.shape[0]
@@ -303,7 +304,8 @@ def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq,
                                      -LN_WS_BLOCKS if ln_slots is not None else LN_WS_BLOCKS, rows,
                                      B, Lq, seq.cap if seq is not None else Lq,
                                      seq.offs.data_ptr() if seq is not None else None, _WGRAD_TARGET, _stream(),
-                                     None if wgrad_stream is None else wgrad_stream.cuda_stream), "block_bwd")
+                                     None if wgrad_stream is None else wgrad_stream.cuda_stream, _p(dx8), _p(din8),
+                                     _p(din8_scale), _p(din8_amax)), "block_bwd")
 
 
 class PackedSeq(object):

@@ -113,8 +113,9 @@ def test_weight_quantisation_and_delayed_scaling():
         amax.copy_(first * bump)
         L.check(h.ilvlm_fp8_scale_update(amax.data_ptr(), hist.data_ptr(), scale.data_ptr(), inv.data_ptr(), fmt_max.data_ptr(), 3, 4,
                                          pos % 4, torch.cuda.current_stream().cuda_stream), "scale_update")
-        assert float(amax.abs().max()) == 0.0
         window = [1.0, 0.5, 3.0, 0.25, 0.25, 0.25, 0.25][max(0, pos - 3):pos + 1]
+        # the running amax restarts at 0.9 x the window maximum (keeps the per-wave atomic maxima rare), not at 0
+        assert torch.allclose(amax.cpu(), 0.9 * first.cpu() * max(window), rtol=1e-6)
         want = fmt_max.cpu() / (first.cpu() * max(window))
         assert torch.allclose(scale.cpu(), want, rtol=1e-6) and torch.allclose(inv.cpu(), 1 / want, rtol=1e-6)
 
@@ -186,3 +187,58 @@ def test_fp8_loss_curve_tracks_bf16_at_real_size():
     assert l8[-1] < 0.7 * l8[0]
     gap = max(abs(a - b) for a, b in zip(l8, lb))
     assert gap < 0.1 * lb[0], "largest absolute gap %.4f of an initial loss of %.4f" % (gap, lb[0])
+
+
+def test_fused_fp8_copies_equal_the_separate_quantise_pass():
+    """LayerNorm forward / backward and the GEMM epilogue can emit the fp8 copy of their output themselves (fp8 mode's fused
+    quantisation): same bytes and same amax as quantising the stored output afterwards"""
+    import ctypes as C
+    from ilvlm_amd import ops, lib as L
+    h = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    rows, cols = 777, 768
+    x = rnd(rows, cols, seed=1).cuda()
+    gamma, beta = (1 + 0.1 * rnd(cols, seed=2)).cuda(), (0.1 * rnd(cols, seed=3)).cuda()
+    y = torch.empty(rows, cols, device="cuda", dtype=torch.bfloat16); mean = torch.empty(rows, device="cuda"); rstd = torch.empty_like(mean)
+    y8 = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    scale = torch.tensor([37.0], device="cuda"); amax = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_layernorm_fwd_q8(x.data_ptr(), L.F32, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), L.BF16, mean.data_ptr(),
+                                     rstd.data_ptr(), rows, cols, 1e-5, 0, 0, y8.data_ptr(), scale.data_ptr(), amax.data_ptr(), st), "ln_fwd_q8")
+    # the fused copy is taken from the fp32 values before the bf16 rounding of y: compare against quantising those
+    yf = torch.empty(rows, cols, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, yf, mean, rstd, rows, cols)
+    want = to_f8(yf.cpu(), 37.0, False).view(torch.uint8)
+    got = y8.cpu()
+    assert not bool(((got != want) & ((got & 0x7f) != 0)).any())
+    assert abs(float(amax) - float(yf.abs().max())) <= 1e-6 * float(yf.abs().max())
+    # LayerNorm backward: e5m2 copy of dx_lp
+    dy = (rnd(rows, cols, seed=4) * 1e-3).to(torch.bfloat16).cuda()
+    dg, db = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    dx = torch.empty(rows, cols, device="cuda"); dx_lp = torch.empty(rows, cols, device="cuda", dtype=torch.bfloat16)
+    dx8 = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    s2 = torch.tensor([2.0e4], device="cuda"); a2 = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_layernorm_bwd_q8(dy.data_ptr(), L.BF16, x.data_ptr(), L.F32, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     None, dx.data_ptr(), dx_lp.data_ptr(), L.BF16, 0, None, dg.data_ptr(), db.data_ptr(), rows, cols,
+                                     0, 0, None, 1, dx8.data_ptr(), s2.data_ptr(), a2.data_ptr(), st), "ln_bwd_q8")
+    want = to_f8(dx.cpu(), 2.0e4, True).view(torch.uint8)
+    got = dx8.cpu()
+    assert not bool(((got != want) & ((got & 0x7f) != 0)).any())
+    assert abs(float(a2) - float(dx.abs().max())) <= 1e-6 * float(dx.abs().max())
+    # GEMM epilogue: QuickGELU forward with the activation's e4m3 copy, ragged rows (generic path on the last row tile)
+    M, N, K = 300, 256, 128
+    a = rnd(M, K, seed=5).to(torch.bfloat16).cuda(); w = (rnd(N, K, seed=6) * 0.1).to(torch.bfloat16).cuda()
+    bias = rnd(N, seed=7).cuda()
+    g = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); u = torch.empty_like(g)
+    g8 = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+    s3 = torch.tensor([55.0], device="cuda"); a3 = torch.zeros(1, device="cuda")
+    epi = L.GemmEpilogue(bias.data_ptr(), None, None, u.data_ptr(), None, 1.0, 1, L.BF16, 0, 0, 0, None, None, None, None, 0, None,
+                         g8.data_ptr(), s3.data_ptr(), a3.data_ptr(), 0)
+    L.check(h.ilvlm_gemm(L.BF16, 0, 0, M, N, K, a.data_ptr(), K, w.data_ptr(), K, g.data_ptr(), N, C.byref(epi), 1, st), "gemm out8")
+    pre = a.float() @ w.float().t() + bias
+    gf = O.quick_gelu(pre).cpu()
+    want = to_f8(gf, 55.0, False)
+    got = g8.cpu().view(torch.float8_e4m3fn)
+    # fp32 sums differ in the last bit between the MFMA order and torch: allow one fp8 code of difference at rounding ties
+    d = (got.float() - want.float()).abs()
+    assert float(d.max()) <= 0.13 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
+    assert abs(float(a3) - float(gf.abs().max())) < 1e-3 * float(gf.abs().max())
