@@ -33,3 +33,24 @@ for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
         print("%-14s M=%6d N=%5d K=%5d  bf16 %6.1f us %5.0f TF   fp8 %6.1f us %5.0f TF   x%.2f" % (
             tag + "." + name, M, n, k, tb, fl / tb / 1e6, t8, fl / t8 / 1e6, tb / t8), flush=True)
 print("sum bf16 %.0f us, fp8 %.0f us, x%.2f" % (tot[0], tot[1], tot[0] / tot[1]))
+
+# weight gradients: dW[out, in] += dY^T X, both operands K-strided, split-K atomics
+tot = [0.0, 0.0]
+for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
+    for name, n_out, n_in in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E)):
+        dy = torch.randn(M, n_out, device="cuda").to(torch.bfloat16); x = torch.randn(M, n_in, device="cuda").to(torch.bfloat16)
+        dy8 = torch.randint(0, 120, (M, n_out), device="cuda", dtype=torch.uint8)
+        x8 = torch.randint(0, 120, (M, n_in), device="cuda", dtype=torch.uint8)
+        dw = torch.zeros(n_out, n_in, device="cuda"); db = torch.zeros(n_out, device="cuda")
+        sk = ops.wgrad_split(n_out, n_in, M)
+        tb = t_of(lambda: ops.gemm(dy, x, dw, trans_a=True, trans_b=True, accumulate=True, split_k=sk, a_rowsum=db))
+        best = (1e9, 0)
+        for s8 in sorted({sk, max(1, sk // 2), min(16, sk * 2)}):
+            t = t_of(lambda: ops.gemm_fp8_wgrad(dy8, x8, dw, one, one, split_k=s8, rowsum=db))
+            best = min(best, (t, s8))
+        t8 = t_of(lambda: ops.gemm_fp8_wgrad(dy8, x8, dw, one, one, split_k=sk, rowsum=db))
+        fl = 2.0 * M * n_out * n_in
+        tot[0] += tb; tot[1] += t8
+        print("%-14s out=%5d in=%5d T=%6d split %2d  bf16 %6.1f us %5.0f TF   fp8 %6.1f us %5.0f TF  x%.2f  (best fp8 %.1f us at split %d)" % (
+            tag + "." + name + ".wgrad", n_out, n_in, M, sk, tb, fl / tb / 1e6, t8, fl / t8 / 1e6, tb / t8, best[0], best[1]), flush=True)
+print("wgrad sum bf16 %.0f us, fp8 %.0f us, x%.2f" % (tot[0], tot[1], tot[0] / tot[1]))

@@ -56,8 +56,10 @@ const char* ilvlm_last_error(void);
  * compute_dtype ILVLM_BF16: A,B bf16 -> v_mfma_f32_16x16x32_bf16, fp32 accumulate.
  * compute_dtype ILVLM_F32 : A,B f32  -> v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
  * compute_dtype ILVLM_FP8 / ILVLM_FP8_BF8A: A,B fp8 bytes (OCP e4m3; _BF8A: A is e5m2) -> v_mfma_f32_16x16x32_fp8_*,
- *   fp32 accumulate; (0,0) layout only, K % 128 == 0, lda / ldb in elements (= bytes); the de-quantisation scales go
- *   through alpha_ptr / alpha_ptr2; aux (activation epilogues) is bf16, out is bf16 or fp32 (BASELINE configs[4]).
+ *   fp32 accumulate; (0,0) layout with K % 128 == 0, or -- ILVLM_FP8_BF8A only -- the weight-gradient form (1,1) with
+ *   accumulate = 1 (A = dY [K, M] e5m2, B = X [K, N] e4m3, any K, M and N multiples of 16; a_rowsum is de-quantised by
+ *   alpha_ptr alone); lda / ldb in elements (= bytes); the de-quantisation scales go through alpha_ptr (A) / alpha_ptr2
+ *   (B); aux (activation epilogues) is bf16, out is bf16 or fp32 (BASELINE configs[4]).
  * Epilogue, in this order: acc *= alpha * (alpha_ptr ? *alpha_ptr : 1); += bias[n];
  *   += rowbias[(out_skip + m % out_group) * N + n]; activation (see ILVLM_ACT_*; aux is [M,N] with
  *   stride ldc, dtype = compute_dtype); += residual (fp32, laid out like C); store as out_dtype
@@ -293,7 +295,8 @@ typedef struct ilvlm_block {
     /* fp8 mode (BASELINE configs[4]); fp8 = 0 and NULL pointers otherwise.  fp8 = 1: bf16 GEMMs, only the amaxes of the
      * tensors that would be quantised are recorded (first step: no scale history yet); fp8 = 2: the four forward GEMMs take
      * e4m3 activations x e4m3 weights and the four input-gradient GEMMs e5m2 gradients x transposed e4m3 weights, weight
-     * gradients stay bf16.  f8_scale / f8_inv / f8_amax: 12 floats each, in the order h1, att, h2, g (GEMM inputs),
+     * gradients stay bf16; fp8 = 3: the weight gradients too (e5m2 gradient copies x the e4m3 activation copies the forward
+     * call left in `saved`; forward and backward must agree on fp8 >= 2).  f8_scale / f8_inv / f8_amax: 12 floats each, in the order h1, att, h2, g (GEMM inputs),
      * in_w, out_w, fc_w, proj_w, d(x_out), du, d(x_mid), dqkv (gradients). */
     const void *in_w8, *out_w8, *fc_w8, *proj_w8;       /* e4m3, the weights' own [out, in] layout */
     const void *in_w8t, *out_w8t, *fc_w8t, *proj_w8t;   /* e4m3, transposed [in, out] */

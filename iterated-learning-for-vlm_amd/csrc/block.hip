@@ -14,7 +14,7 @@ inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline int esz(int dtype) { return dtype == ILVLM_BF16 ? 2 : 4; }
 
 struct Saved {   // byte offsets into the saved-activation workspace of one block
-    size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, q8, total;
+    size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, h1_8, att8, h2_8, g8, total;
     Saved(const ilvlm_block* b, long rows, int B, int L) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
@@ -30,13 +30,21 @@ struct Saved {   // byte offsets into the saved-activation workspace of one bloc
         mean2 = o; o += al(r * 4);
         rstd2 = o; o += al(r * 4);
         lse = o; o += al((size_t)B * b->H * L * 4);
-        q8 = o; if (b->fp8 == 2) o += al(r * E) + al(r * 4 * E);   // fp8 copies: E-wide GEMM input, 4E-wide MLP activation
+        // e4m3 copies of the four GEMM inputs; each keeps its own region because the backward pass reads them again as the
+        // X operand of the fp8 weight gradients (7 E bytes per row)
+        h1_8 = att8 = h2_8 = g8 = o;
+        if (b->fp8 >= 2) {
+            h1_8 = o; o += al(r * E);
+            att8 = o; o += al(r * E);
+            h2_8 = o; o += al(r * E);
+            g8 = o; o += al(r * 4 * E);
+        }
         total = o;
     }
 };
 
 struct Scratch {   // backward temporaries
-    size_t du, dh2, dmid, dmid_lp, da, dqkv, dh1, q8, total;
+    size_t du, dh2, dmid, dmid_lp, da, dqkv, dh1, dout8, du8, dmid8, dqkv8, total;
     Scratch(const ilvlm_block* b, long rows) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
@@ -47,7 +55,15 @@ struct Scratch {   // backward temporaries
         da = o; o += al(r * E * es);
         dqkv = o; o += al(r * 3 * E * es);
         dh1 = o; o += al(r * E * es);
-        q8 = o; if (b->fp8 == 2) o += al(r * E) + al(r * 4 * E);   // e5m2 copies: E-wide gradient, up to 4E-wide gradient
+        // e5m2 copies of the four gradients: separate regions, the weight-gradient stream reads each one while the main
+        // stream is already producing the next (9 E bytes per row)
+        dout8 = du8 = dmid8 = dqkv8 = o;
+        if (b->fp8 >= 2) {
+            dout8 = o; o += al(r * E);
+            du8 = o; o += al(r * 4 * E);
+            dmid8 = o; o += al(r * E);
+            dqkv8 = o; o += al(r * 3 * E);
+        }
         total = o;
     }
 };
@@ -58,9 +74,9 @@ int check_block(const ilvlm_block* b, const char* who) {
     ILVLM_REQUIRE(b->E > 0 && b->H > 0 && b->E == 64 * b->H, "%s: width %d must be 64 x heads (%d)", who, b->E, b->H);
     ILVLM_REQUIRE(b->ln1_w && b->ln1_b && b->ln2_w && b->ln2_b && b->in_w && b->in_b && b->out_w && b->out_b && b->fc_w &&
                       b->fc_b && b->proj_w && b->proj_b, "%s: null parameter pointer", who);
-    ILVLM_REQUIRE(b->fp8 >= 0 && b->fp8 <= 2, "%s: bad fp8 mode %d", who, b->fp8);
+    ILVLM_REQUIRE(b->fp8 >= 0 && b->fp8 <= 3, "%s: bad fp8 mode %d", who, b->fp8);
     ILVLM_REQUIRE(!b->fp8 || b->dtype == ILVLM_BF16, "%s: fp8 mode needs bf16 storage", who);
-    ILVLM_REQUIRE(b->fp8 != 2 || (b->in_w8 && b->out_w8 && b->fc_w8 && b->proj_w8 && b->in_w8t && b->out_w8t && b->fc_w8t &&
+    ILVLM_REQUIRE(b->fp8 < 2 || (b->in_w8 && b->out_w8 && b->fc_w8 && b->proj_w8 && b->in_w8t && b->out_w8t && b->fc_w8t &&
                                   b->proj_w8t && b->E % 128 == 0), "%s: fp8 mode needs the fp8 weights and E %% 128 == 0", who);
     return ILVLM_OK;
 }
@@ -106,11 +122,13 @@ int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, 
 }
 
 // dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s.
-// dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given.
+// dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given; x8 / inv_x: the
+// weight gradient on fp8 operands too (e5m2 dy^T, the e4m3 activation copy the forward pass kept), bias gradient as its row sums.
 int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
                int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
                const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr, void* dx8 = nullptr,
-               const float* dx8_scale = nullptr, float* dx8_amax = nullptr) {
+               const float* dx8_scale = nullptr, float* dx8_amax = nullptr, const void* x8 = nullptr,
+               const float* inv_x = nullptr) {
     const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
     if (gW || gb) {
         hipStream_t ws = s;
@@ -131,8 +149,14 @@ int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* g
             ep.out_dtype = ILVLM_F32;
             ep.accumulate = 1;
             ep.a_rowsum = fuse_b ? gb : nullptr;
-            TRY(ilvlm_gemm(dtype, 1, 1, N, K, (int)M, dy, N, x, K, gW, K, &ep,
-                           wgrad_split(N, K, M, dtype == ILVLM_BF16 ? 128 : 64, wgrad_target), ws));
+            const int split = wgrad_split(N, K, M, dtype == ILVLM_BF16 ? 128 : 64, wgrad_target);
+            if (dy8 && x8) {
+                ep.alpha_ptr = inv_g;
+                ep.alpha_ptr2 = inv_x;
+                TRY(ilvlm_gemm(ILVLM_FP8_BF8A, 1, 1, N, K, (int)M, dy8, N, x8, K, gW, K, &ep, split, ws));
+            } else {
+                TRY(ilvlm_gemm(dtype, 1, 1, N, K, (int)M, dy, N, x, K, gW, K, &ep, split, ws));
+            }
         }
         if (gb && !fuse_b) TRY(ilvlm_colsum(dy, dtype, gb, M, N, N, ws));
     }
@@ -179,22 +203,21 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     // fp8 mode: the fp8 copy of each GEMM input is emitted by its producer where that is a kernel of this library with the
     // values in registers (LayerNorm, the fc GEMM's QuickGELU epilogue); the attention output takes a quantise pass
     hipStream_t s = (hipStream_t)stream;
-    const bool f8on = b->fp8 == 2, f8obs = b->fp8 != 0;
-    void* q8a = w + o.q8;                           // [rows, E] bytes
-    void* q8g = w + o.q8 + al((size_t)rows * E);    // [rows, 4E] bytes
+    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0;
+    void *h1_8 = w + o.h1_8, *att8 = w + o.att8, *h2_8 = w + o.h2_8, *g8 = w + o.g8;
     const float* sc = b->f8_scale;
     float* am = b->f8_amax;
     const void* x8;
-    TRY(ilvlm_layernorm_fwd_q8(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, f8on ? q8a : nullptr,
+    TRY(ilvlm_layernorm_fwd_q8(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, f8on ? h1_8 : nullptr,
                                f8on ? sc + F8_H1 : nullptr, f8obs ? am + F8_H1 : nullptr, stream));
     ilvlm_gemm_epilogue ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->in_b;
-    TRY(linear_fwd(b, h1, f8on ? q8a : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
+    TRY(linear_fwd(b, h1, f8on ? h1_8 : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
     if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
     else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
-    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, q8a, s, &x8));
+    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, att8, s, &x8));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
@@ -202,7 +225,7 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.residual = x_in;
     TRY(linear_fwd(b, att, x8, F8_ATT, b->out_w, b->out_w8, F8_OUT_W, x_mid, rows, E, E, ep, s));
     // x_out = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
-    TRY(ilvlm_layernorm_fwd_q8(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, f8on ? q8a : nullptr,
+    TRY(ilvlm_layernorm_fwd_q8(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, f8on ? h2_8 : nullptr,
                                f8on ? sc + F8_H2 : nullptr, f8obs ? am + F8_H2 : nullptr, stream));
     ep = {};
     ep.alpha = 1.0f;
@@ -211,18 +234,18 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.aux = u;
     ep.act = ILVLM_ACT_QUICKGELU;
     if (f8obs) {                                    // the activation's fp8 copy (and amax) straight from the epilogue
-        ep.out8 = f8on ? q8g : nullptr;
+        ep.out8 = f8on ? g8 : nullptr;
         ep.out8_scale = f8on ? sc + F8_G : nullptr;
         ep.out8_amax = am + F8_G;
         ep.out8_fmt = 0;
     }
-    TRY(linear_fwd(b, h2, f8on ? q8a : nullptr, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s));
+    TRY(linear_fwd(b, h2, f8on ? h2_8 : nullptr, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->proj_b;
     ep.residual = x_mid;
-    return linear_fwd(b, g, f8on ? q8g : nullptr, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s);
+    return linear_fwd(b, g, f8on ? g8 : nullptr, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s);
 }
 
 extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32,
@@ -255,9 +278,12 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // fp8 mode: e5m2 copies of the gradients entering the four input-gradient GEMMs.  d(x_out) arrives from the caller when
     // the previous call (the next block) emitted it (din8); du comes out of the proj input-gradient GEMM's epilogue, d(x_mid)
     // out of ln_2's backward, dqkv takes a quantise pass; ln_1's backward emits the next call's d(x_out) into din8.
-    const bool f8on = b->fp8 == 2, f8obs = b->fp8 != 0;
-    void* q8e = t + c.q8;                             // [rows, E]
-    void* q8w = t + c.q8 + al((size_t)rows * E);      // [rows, <= 4E]
+    // fp8 == 3: the four weight gradients take fp8 operands as well (the e5m2 gradient copies x the e4m3 activation copies
+    // kept by the forward pass)
+    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0, f8wg = b->fp8 == 3;
+    void *dout8 = t + c.dout8, *du8 = t + c.du8, *dmid8 = t + c.dmid8, *dqkv8 = t + c.dqkv8;
+    const void *h1_8 = f8wg ? w + o.h1_8 : nullptr, *att8 = f8wg ? w + o.att8 : nullptr, *h2_8 = f8wg ? w + o.h2_8 : nullptr,
+               *g8a = f8wg ? w + o.g8 : nullptr;
     const float* sc = b->f8_scale;
     const float* inv = b->f8_inv;
     float* am = b->f8_amax;
@@ -265,26 +291,26 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     ILVLM_REQUIRE(!(dx8 || din8) || f8on, "block_bwd: fp8 gradient copies only in active fp8 mode");
     ILVLM_REQUIRE(!din8 || din8_scale, "block_bwd: din8 needs its scale");
     if (dx8) g8 = dx8;
-    else TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, q8e, s, &g8));
+    else TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, dout8, s, &g8));
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
-                   g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? q8w : nullptr, f8on ? sc + F8_DU : nullptr,
-                   f8obs ? am + F8_DU : nullptr));
+                   g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,
+                   f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G));
     TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
-                   f8on ? q8w : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W));
+                   f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
     TRY(ilvlm_layernorm_bwd_q8(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
-                               b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, f8on ? q8e : nullptr, f8on ? sc + F8_DMID : nullptr,
+                               b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, f8on ? dmid8 : nullptr, f8on ? sc + F8_DMID : nullptr,
                                f8obs ? am + F8_DMID : nullptr, s));
     // attention
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
     TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
-                   f8on ? q8e : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W));
+                   f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT));
     if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
     else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
-    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, q8w, s, &g8));
+    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, dqkv8, s, &g8));
     TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
-                   inv + F8_DQKV, inv + F8_IN_W));
+                   inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1));
     return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
                                   nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, din8, din8_scale, din8_amax, s);
 }

@@ -9,6 +9,7 @@
 // Replaces F.linear / matmul call sites listed in include/ilvlm_hip.h.
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -407,6 +408,53 @@ struct DmaOperand {
                                                      16, voff[TR ? j : 0], soff + (TR ? 0 : j * jstep), 0, 0);
     }
 };
+
+// K-strided fp8 operand (weight gradients in fp8 mode: A = dY [tokens, out] e5m2, B = X [tokens, in] e4m3, the token index is
+// the reduction).  K-tile = 128 k-rows x 128 bytes (= 128 operand rows): a DMA piece is 8 k-rows of 128 contiguous bytes.
+// Fragments come from ds_read_b64_tr_b8, whose lane map was measured (benchmarks/micro/tr8_probe.hip): within a group of
+// 16 lanes, lane s supplies the address of 8 contiguous bytes of block row s >> 1, columns 8 (s & 1) .. +7, and lane i
+// receives column i of the 8 rows -- with block rows = k and columns = operand rows that is exactly the fp8 16x16x32 MFMA
+// operand (lane l: row l & 15, k = 8 (l >> 4) + j), one read per fragment.  The 16-byte chunk c of k-row r is stored at
+// slot c ^ ((r >> 1) & 7): the 16 k-rows a 32-lane half reads then cover all 64 banks once.
+template <int ROWS, int NTHREADS>
+struct DmaOperandTr8 {
+    static_assert(ROWS == 128, "128-byte k-rows");
+    static constexpr int KT = 128;
+    static constexpr int NLOAD = KT * ROWS / (NTHREADS * 16);
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[NLOAD];
+    int tile_off, k_step;
+    __device__ __forceinline__ void init(const bf16* base, int ld, int r0, int R, int K, int wave, int lane) {
+        const long bytes = (long)(K - 1) * ld + R;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j) {
+            const int s = (wave * NLOAD + j) * 64 + lane;
+            const int kr = s >> 3, slot = s & 7;
+            voff[j] = kr * ld + ((slot ^ ((kr >> 1) & 7)) << 4);
+        }
+        tile_off = r0;
+        k_step = KT * ld;
+    }
+    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
+        const int soff = tile_off + t * k_step + extra;
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
+                                                     16, voff[j], soff, 0, 0);
+    }
+};
+
+__device__ __forceinline__ long tr8_frag(const unsigned char* tile, int r16, int k32, int lane) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i lds_v2i;
+    const int i = lane & 15, g = lane >> 4;
+    const int kr = k32 + 8 * g + (i >> 1);
+    const int chunk = (r16 >> 4) ^ ((kr >> 1) & 7);
+    union { v2i v; long l; } u;
+    u.v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(tile + 128 * kr + 16 * chunk + 8 * (i & 1)));
+    return u.l;
+}
 #endif
 
 // Tile epilogue for SWAP fragments (lane owns row (l&15) and 4 consecutive columns 4*(l>>4).. of each 16x16 tile).
@@ -597,8 +645,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     constexpr int NT = 64 * WM * WN;
     constexpr int TI = DBM / WM / 16, TJ = DBN / WN / 16;      // 16x16 tiles per wave
     constexpr int A_BYTES = DBM * BKT * 2, STAGE = (DBM + DBN) * BKT * 2;
-    typedef DmaOperand<TA, DBM, NT, BKT> OpA;
-    typedef DmaOperand<TB, DBN, NT, BKT> OpB;
+    constexpr bool TR8 = FP8 == 3;          // K-strided fp8 operands (fp8 weight gradients): K-tile = 128 k-rows
+    static_assert(!TR8 || (TA && TB && !SWAP && DBM == 128 && DBN == 128 && BKT == 64), "fp8 weight-gradient form");
+    constexpr int KTILE = TR8 ? 128 : BKT;
+    typedef typename std::conditional<TR8, DmaOperandTr8<DBM, NT>, DmaOperand<TA, DBM, NT, BKT>>::type OpA;
+    typedef typename std::conditional<TR8, DmaOperandTr8<DBN, NT>, DmaOperand<TB, DBN, NT, BKT>>::type OpB;
     constexpr int LOADS = OpA::NLOAD + OpB::NLOAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -614,7 +665,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     if (!SWAP) { tm = wg % tiles_m; z = wg / tiles_m; }
     else { z = wg % split_k; tm = wg / split_k; }
     const int m0 = tm * DBM, n0 = tn * DBN;
-    const int nt_total = (K + BKT - 1) / BKT;          // a partial last tile only with two K-strided operands (host check)
+    const int nt_total = (K + KTILE - 1) / KTILE;      // a partial last tile only with two K-strided operands (host check)
     const int per = (nt_total + split_k - 1) / split_k;
     const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
     if (t_begin >= t_end) return;
@@ -694,6 +745,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #if ILVLM_GEMM_ABLATE == 1
         if (K < 0)
 #endif
+        if constexpr (TR8) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                long fa8[TI], fb8[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa8[i] = tr8_frag(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) fb8[j] = tr8_frag(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb8[j], fa8[i], acc[i][j], 0, 0, 0);
+                if (rowsum) {     // e4m3 1.0 = 0x38
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(0x3838383838383838L, fa8[i], accb[i], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 fa[TI], fb[TJ];
@@ -705,7 +776,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {    // C^T fragments: lane owns row (l & 15), 4 consecutive columns
-                    if constexpr (FP8 == 0) {
+                    if constexpr (FP8 == 0 || FP8 == 3) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     } else {
                         union { bf16x8 v; long l[2]; } ua, ub;
@@ -764,10 +835,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
         // split-K accumulate: atomics in whole 256-byte row segments (see epilogue_acc_tile)
         epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
         if (rowsum && lane < 16) {
+            // fp8 operands: the row sums are sums of quantised values, de-quantised by the A operand's scale alone
+            const float ra = (FP8 != 0 && ep.e.alpha_ptr) ? *ep.e.alpha_ptr : 1.f;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int m = mw + i * 16 + lane;
-                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][0]);
+                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][0] * ra);
             }
         }
     }
@@ -1197,14 +1270,18 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ILVLM_REQUIRE(!(epi->out8 || epi->out8_amax) || ((fp8 || compute_dtype == ILVLM_BF16) && !epi->accumulate && !epi->pool_out &&
                                                      epi->out_group == 0 && (epi->out8_fmt == 0 || epi->out8_fmt == 1)),
                   "gemm: the fp8 output copy needs bf16 / fp8 compute, no accumulate / pool epilogue, compact rows");
-    ILVLM_REQUIRE(!fp8 || (!trans_a && !trans_b && !epi->accumulate && !epi->a_rowsum && !epi->pool_out && K % 128 == 0 &&
-                           lda % 16 == 0 && ldb % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0),
-                  "gemm fp8: K-contiguous operands only (trans_a = trans_b = 0), no accumulate, K %% 128 == 0, 16-byte aligned rows");
+    const bool fp8_wgrad = compute_dtype == ILVLM_FP8_BF8A && trans_a && trans_b && epi->accumulate;
+    ILVLM_REQUIRE(!fp8 || fp8_wgrad || (!trans_a && !trans_b && !epi->accumulate && !epi->a_rowsum && K % 128 == 0),
+                  "gemm fp8: (0,0) layout without accumulate and K %% 128 == 0, or the weight-gradient form (1,1) with accumulate "
+                  "and an e5m2 A operand");
+    ILVLM_REQUIRE(!fp8 || (!epi->pool_out && lda % 16 == 0 && ldb % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0),
+                  "gemm fp8: 16-byte aligned rows, no pool epilogue");
+    ILVLM_REQUIRE(!fp8_wgrad || (M % 16 == 0 && N % 16 == 0), "gemm fp8 weight gradient: M and N must be multiples of 16");
     ILVLM_REQUIRE(!(epi->act && !epi->aux), "gemm: activation needs aux");
     ILVLM_REQUIRE(!(epi->rowbias && epi->out_group <= 0), "gemm: rowbias needs out_group");
     ILVLM_REQUIRE(epi->act >= 0 && epi->act <= ILVLM_ACT_GELU_ERF_BWD, "gemm: bad act %d", epi->act);
-    ILVLM_REQUIRE(!(epi->a_rowsum && !(epi->accumulate && compute_dtype == ILVLM_BF16)),
-                  "gemm: a_rowsum needs accumulate and bf16 compute");
+    ILVLM_REQUIRE(!(epi->a_rowsum && !(epi->accumulate && (compute_dtype == ILVLM_BF16 || fp8_wgrad))),
+                  "gemm: a_rowsum needs accumulate and bf16 compute (or the fp8 weight-gradient form)");
     ILVLM_REQUIRE(!epi->pool_out || (compute_dtype == ILVLM_BF16 && !epi->accumulate && !epi->bias && !epi->rowbias &&
                                      !epi->residual && !epi->act && epi->out_group == 0 &&
                                      ((epi->pool_seq && epi->pool_offs) || epi->pool_group > 0)),
@@ -1223,6 +1300,11 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         ep.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && aligned(C, caln) && (!epi->bias || aligned(epi->bias, 16)) &&
                     (!epi->rowbias || aligned(epi->rowbias, 16)) && (!epi->residual || aligned(epi->residual, 16)) &&
                     (!epi->aux || aligned(epi->aux, auxaln));
+        if (fp8_wgrad) {    // K-strided fp8 operands: byte addressing, K-tiles of 128 reduction rows
+            int nt = ceil_div(K, 128);
+            if (split_k > nt) split_k = nt;
+            return launch_dma<true, true, false, 128, 128, 2, 2, 1, 64, 3>((const bf16*)A, lda, (const bf16*)B, ldb, K, M, N, split_k, ep, s);
+        }
         if (compute_dtype == ILVLM_FP8)
             return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N,
                                                                            1, ep, s);

@@ -112,7 +112,8 @@ class ParamArena:
 class Fp8State:
     """Per-tensor delayed scaling for the fp8 mode (BASELINE.json configs[4]): the QKV / out / MLP GEMMs of both towers run
     on fp8 operands in the forward pass (activations and weights e4m3) and in the input-gradient pass (gradients e5m2,
-    transposed e4m3 weights); weight gradients stay bf16.  Every quantised tensor kind has a SLOT: its scale is derived
+    transposed e4m3 weights) and, unless ILVLM_FP8_WGRAD=0, in the weight-gradient pass (e5m2 gradients x the e4m3
+    activation copies of the forward pass, both K-strided).  Every quantised tensor kind has a SLOT: its scale is derived
     from the amax history of the last HIST steps (ilvlm_fp8_scale_update); the first step runs the bf16 kernels and only
     observes the amaxes (there is no history to scale by yet)."""
     HIST = 16
@@ -218,6 +219,8 @@ class Engine:
         self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
         self.defer_ln = os.environ.get("ILVLM_DEFER_LN", "1") == "1"      # one LayerNorm-gradient reduction per tower
         self._f8_carry = None
+        # fp8 mode: weight gradients on fp8 operands as well (e5m2 gradient copies x the e4m3 activation copies of the forward)
+        self.fp8_wgrad = os.environ.get("ILVLM_FP8_WGRAD", "1") == "1"
         self._ln_defer = {}
         self._blk = {}          # block prefix -> ilvlm_block descriptor (rebuilt when requires_grad flags change)
 
@@ -318,7 +321,7 @@ class Engine:
                     d.f8_amax = f8.amax[base:].data_ptr()
             self._blk[pre] = d
         if d and self.fp8 is not None:
-            d.fp8 = 2 if self.fp8.active else 1
+            d.fp8 = (3 if self.fp8_wgrad else 2) if self.fp8.active else 1
         return d or None
 
     def _mat(self, name):
@@ -326,12 +329,16 @@ class Engine:
         return w if w.dim() == 2 else w.reshape(w.shape[0], -1)
 
     # ------------------------------------------------------------------ helpers
-    def _linear_bwd(self, dy, x, wname, bname, need_dx=True, dx_act=0, dx_aux=None, fp8_keys=None):
+    def _linear_bwd(self, dy, x, wname, bname, need_dx=True, dx_act=0, dx_aux=None, fp8_keys=None, x8=None):
         """dy: [M,N] T; x: [M,K] T.  Accumulates dW (and db) into the gradient arena, returns dx (T) or None.
         fp8_keys = (block prefix, gradient slot, weight slot): the input gradient runs on e5m2 x transposed-e4m3 operands
-        in fp8 mode (the weight gradient stays in the compute dtype)."""
+        in fp8 mode; x8 = (e4m3 copy of x kept by the forward pass, its slot): the weight gradient does too."""
         M, N = dy.shape
         K = x.shape[1]
+        dy8 = None
+        if fp8_keys is not None and self.fp8 is not None:
+            pre, kg, kw_ = fp8_keys
+            dy8 = self.fp8.quant(dy, pre + kg, e5m2=True)
         need_b = bname is not None and self.req[bname]
         fuse_b = need_b and self.req[wname] and self.T == torch.bfloat16 and ops.rowsum_fusable(N, M)
         wg = self._wgrad_stream()
@@ -343,9 +350,13 @@ class Engine:
             keep = self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, [])
             keep.append(dy)
             keep.append(x)       # x may be a temporary of the caller (the un-padded patch rows of a trainable conv1)
+            keep.append(dy8)
             ops._stream_override = wg.cuda_stream          # cheaper than entering a torch stream context per GEMM
         try:
-            if self.req[wname]:
+            if self.req[wname] and dy8 is not None and x8 is not None and x8[0] is not None:
+                ops.gemm_fp8_wgrad(dy8, x8[0], self.Gr[wname].reshape(N, -1), self.fp8.s(pre + kg)[1], self.fp8.s(pre + x8[1])[1],
+                                   split_k=ops.wgrad_split(N, K, M, 128), rowsum=self.Gr[bname] if fuse_b else None)
+            elif self.req[wname]:
                 # dW[N,K] += dy^T x ; the bias gradient sum_m dy[m,:] rides along as the row sums of the A operand
                 ops.gemm(dy, x, self.Gr[wname].reshape(N, -1), trans_a=True, trans_b=True, accumulate=True,
                          split_k=ops.wgrad_split(N, K, M, 128 if self.T == torch.bfloat16 else 64),
@@ -357,10 +368,6 @@ class Engine:
         if not need_dx:
             return None
         dx = _empty((M, K), self.T, dy)
-        dy8 = None
-        if fp8_keys is not None and self.fp8 is not None:
-            pre, kg, kw_ = fp8_keys
-            dy8 = self.fp8.quant(dy, pre + kg, e5m2=True)
         if dy8 is not None:
             ops.gemm_fp8(dy8, self.fp8.w8(pre, kw_, transposed=True), dx, self.fp8.s(pre + kg)[1], self.fp8.s(pre + kw_)[1],
                          a_e5m2=True, aux=dx_aux, act=dx_act)
@@ -389,22 +396,25 @@ class Engine:
                 ops.gemm_fp8(x8, f8.w8(pre, key_w), out, f8.s(pre + key_a)[1], f8.s(pre + key_w)[1], **kw)
             else:
                 ops.gemm(x, self._mat(pre + wname), out, **kw)
+            return x8
 
         h1 = _empty((M, E), T, x_in); mean1 = _empty((M,), torch.float32, x_in); rstd1 = torch.empty_like(mean1)
         ops.layernorm_fwd(x_in, Wf[pre + "ln_1.weight"], Wf[pre + "ln_1.bias"], h1, mean1, rstd1, M, E)
         qkv = _empty((M, 3 * E), T, x_in)
-        lin(h1, "h1", "in_w", "attn.in_proj_weight", qkv, bias=Wf[pre + "attn.in_proj_bias"])
+        h1_8 = lin(h1, "h1", "in_w", "attn.in_proj_weight", qkv, bias=Wf[pre + "attn.in_proj_bias"])
         att = _empty((M, E), T, x_in); lse = _empty((B, H, L), torch.float32, x_in)
         ops.attention_fwd(qkv, att, lse, B, L, H, causal, seq)
         x_mid = _empty((M, E), torch.float32, x_in)
-        lin(att, "att", "out_w", "attn.out_proj.weight", x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
+        att8 = lin(att, "att", "out_w", "attn.out_proj.weight", x_mid, bias=Wf[pre + "attn.out_proj.bias"], residual=x_in)
         h2 = _empty((M, E), T, x_in); mean2 = torch.empty_like(mean1); rstd2 = torch.empty_like(mean1)
         ops.layernorm_fwd(x_mid, Wf[pre + "ln_2.weight"], Wf[pre + "ln_2.bias"], h2, mean2, rstd2, M, E)
         u = _empty((M, 4 * E), T, x_in); g = _empty((M, 4 * E), T, x_in)
-        lin(h2, "h2", "fc_w", "mlp.c_fc.weight", g, bias=Wf[pre + "mlp.c_fc.bias"], aux=u, act=ACT_QUICKGELU)
+        h2_8 = lin(h2, "h2", "fc_w", "mlp.c_fc.weight", g, bias=Wf[pre + "mlp.c_fc.bias"], aux=u, act=ACT_QUICKGELU)
         x_out = _empty((M, E), torch.float32, x_in)
-        lin(g, "g", "proj_w", "mlp.c_proj.weight", x_out, bias=Wf[pre + "mlp.c_proj.bias"], residual=x_mid)
-        saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g) if save else None
+        g8 = lin(g, "g", "proj_w", "mlp.c_proj.weight", x_out, bias=Wf[pre + "mlp.c_proj.bias"], residual=x_mid)
+        # the e4m3 copies are the X operands of the fp8 weight gradients
+        x8s = (h1_8, att8, h2_8, g8) if (self.fp8_wgrad and g8 is not None) else (None,) * 4
+        saved = (x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g, x8s) if save else None
         return x_out, saved
 
     def _ln_defer_begin(self, tower, n_blocks, E):
@@ -448,6 +458,8 @@ class Engine:
             if wg is not None:    # the scratch holds the dY operands of the weight-gradient GEMMs: alive until the join
                 self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).append(scratch)
                 self._wg_keep[torch.cuda.current_stream().cuda_stream].append(dx_lp if lp else dx_f32)
+                if f8_in is not None:     # the e5m2 copy of dx is the dY operand of this block's proj weight gradient
+                    self._wg_keep[torch.cuda.current_stream().cuda_stream].append(f8_in)
             # fp8 mode: f8_in = e5m2 copy of dx_lp made by the block processed before this one; f8_next = prefix of the block
             # that consumes this call's input gradient (its d(x_out) slot scales the copy this call emits)
             din8 = sc8 = am8 = None
@@ -459,25 +471,27 @@ class Engine:
                           din8_amax=am8)
             self._f8_carry = din8
             return din, din_lp
-        x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g = saved
+        x_in, h1, mean1, rstd1, qkv, att, lse, x_mid, h2, mean2, rstd2, u, g, (h1_8, att8, h2_8, g8) = saved
         M, E = x_in.shape
         T, Wf, Gr = self.T, self.Wf, self.Gr
         lp = T != torch.float32
         dy = dx_lp if lp else dx_f32
         # MLP: x_out = x_mid + c_proj(quickgelu(c_fc(h2)))
         du = self._linear_bwd(dy, g, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dx_act=ACT_QUICKGELU_BWD, dx_aux=u,
-                              fp8_keys=(pre, "dout", "proj_w"))
-        dh2 = self._linear_bwd(du, h2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", fp8_keys=(pre, "du", "fc_w"))
+                              fp8_keys=(pre, "dout", "proj_w"), x8=(g8, "g"))
+        dh2 = self._linear_bwd(du, h2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", fp8_keys=(pre, "du", "fc_w"), x8=(h2_8, "h2"))
         dmid = _empty((M, E), torch.float32, x_in)
         dmid_lp = _empty((M, E), T, x_in) if lp else None
         ops.layernorm_bwd(dh2, x_mid, mean2, rstd2, Wf[pre + "ln_2.weight"], Gr[pre + "ln_2.weight"], Gr[pre + "ln_2.bias"],
                           M, E, dres=dx_f32, dx_f32=dmid, dx_lp=dmid_lp)
         dy = dmid_lp if lp else dmid
         # attention: x_mid = x_in + out_proj(attn(in_proj(h1)))
-        da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias", fp8_keys=(pre, "dmid", "out_w"))
+        da = self._linear_bwd(dy, att, pre + "attn.out_proj.weight", pre + "attn.out_proj.bias", fp8_keys=(pre, "dmid", "out_w"),
+                              x8=(att8, "att"))
         dqkv = _empty((M, 3 * E), T, x_in)
         ops.attention_bwd(da, qkv, att, lse, dqkv, B, L, H, causal, seq)
-        dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias", fp8_keys=(pre, "dqkv", "in_w"))
+        dh1 = self._linear_bwd(dqkv, h1, pre + "attn.in_proj_weight", pre + "attn.in_proj_bias", fp8_keys=(pre, "dqkv", "in_w"),
+                               x8=(h1_8, "h1"))
         din = _empty((M, E), torch.float32, x_in)
         din_lp = _empty((M, E), T, x_in) if lp else None
         ops.layernorm_bwd(dh1, x_in, mean1, rstd1, Wf[pre + "ln_1.weight"], Gr[pre + "ln_1.weight"], Gr[pre + "ln_1.bias"],

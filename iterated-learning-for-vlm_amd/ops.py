@@ -179,6 +179,32 @@ def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual
     return out
 
 
+def gemm_fp8_wgrad(dy8, x8, out, scale_dy, scale_x, *, split_k=1, rowsum=None, K=None):
+    """out[m,n] += inv_dy * inv_x * sum_t dy8[t,m] x8[t,n] (weight gradient in fp8 mode): dy8 [T,M] uint8 holding e5m2,
+    x8 [T,N] uint8 holding e4m3, out fp32 [M,N]; rowsum[m] += inv_dy * sum_t dy8[t,m] (bias gradient)."""
+    _chk(dy8, "gemm_fp8_wgrad.dy", torch.uint8); _chk(x8, "gemm_fp8_wgrad.x", torch.uint8)
+    _chk(out, "gemm_fp8_wgrad.out", torch.float32)
+    k = dy8.shape[0] if K is None else K
+    m, n = dy8.shape[1], x8.shape[1]
+    if x8.shape[0] < k or dy8.shape[0] < k or tuple(out.shape) != (m, n):
+        raise RuntimeError("gemm_fp8_wgrad: shapes %s %s -> %s" % (tuple(dy8.shape), tuple(x8.shape), tuple(out.shape)))
+    if rowsum is not None:
+        _chk(rowsum, "gemm_fp8_wgrad.rowsum", torch.float32, (m,))
+    epi = GemmEpilogue(None, None, None, None, scale_dy.data_ptr(), 1.0, 0, L.F32, 1, 0, 0, _p(rowsum),
+                       None, None, None, 0, scale_x.data_ptr())
+    prof = _gemm_profiler
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        ev0.record(est)
+    L.check(L.load().ilvlm_gemm(L.FP8_BF8A, 1, 1, m, n, k, dy8.data_ptr(), dy8.stride(0), x8.data_ptr(), x8.stride(0),
+                                out.data_ptr(), out.stride(0), C.byref(epi), int(split_k), _stream()), "gemm(fp8 wgrad)")
+    if prof is not None:
+        ev1.record(est)
+        prof.records.append((ev0, ev1, 2.0 * m * n * k, 1.0 * (m * k + n * k) + 8.0 * m * n, "fp8"))
+    return out
+
+
 def fp8_quantize(src, dst, scale, amax, e5m2=False):
     """dst (uint8, same shape; None = observe only) = fp8(src * scale[0]); amax[0] = max(amax[0], max|src|)"""
     _chk(src, "fp8_quantize.src")

@@ -76,6 +76,33 @@ def test_fp8_gemm_matches_dequantised_product(M, N, K, a_e5m2):
     assert float((z.cpu() - (pre + res.cpu())).abs().max()) < 1e-4 * float((pre + res.cpu()).abs().max())
 
 
+@pytest.mark.parametrize("T,M,N,split", [(128, 128, 128, 1), (256, 64, 192, 2), (1000, 768, 768, 3), (11319, 512, 2048, 8),
+                                         (77, 16, 48, 1)])
+def test_fp8_weight_gradient_gemm(T, M, N, split):
+    """the (1,1) accumulate form: both operands K-strided fp8 (dY e5m2, X e4m3), any reduction length (rows past T are
+    never read), split-K atomics into an fp32 gradient that already holds a value, bias gradient as a by-product"""
+    from ilvlm_amd import ops
+    dy, x = rnd(T, M, seed=1) * 1e-4, rnd(T, N, seed=2)
+    sd, sx = 57344.0 / float(dy.abs().max()), 448.0 / float(x.abs().max())
+    dy8, x8 = to_f8(dy, sd, True), to_f8(x, sx, False)
+    ref = (dy8.float().t().double() @ x8.float().double()).float() / (sd * sx)
+    inv_d, inv_x = torch.tensor([1.0 / sd], device="cuda"), torch.tensor([1.0 / sx], device="cuda")
+    # operands sit inside larger buffers whose following rows are poison: the kernel must not read past row T
+    D = torch.full((T + 130, M), 0x7b, dtype=torch.uint8, device="cuda"); D[:T] = dy8.view(torch.uint8).cuda()
+    X = torch.full((T + 130, N), 0x7e, dtype=torch.uint8, device="cuda"); X[:T] = x8.view(torch.uint8).cuda()
+    base = rnd(M, N, seed=3) * float(ref.abs().max())
+    out = base.cuda()
+    rs = torch.full((M,), 2.0, device="cuda")
+    ops.gemm_fp8_wgrad(D, X, out, inv_d, inv_x, split_k=split, rowsum=rs, K=T)
+    tol = 2e-4 * float(ref.abs().max()) + 1e-6 * float(base.abs().max())
+    assert float((out.cpu() - base - ref).abs().max()) < tol
+    want_rs = dy8.float().double().sum(0).float() / sd
+    assert float((rs.cpu() - 2.0 - want_rs).abs().max()) < 1e-4 * float(want_rs.abs().max()) + 1e-6
+    # faithful to the unquantised product at fp8 accuracy
+    full = dy.t() @ x
+    assert float((out.cpu() - base - full).abs().max()) < 0.15 * float(full.abs().max())
+
+
 def test_weight_quantisation_and_delayed_scaling():
     """the batched weight kernel: e4m3 copy and its transpose at the tensors' arena offsets, per-tensor amax; the scale
     update: history ring, scale = fmt_max / max(history), amax reset"""
