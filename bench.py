@@ -44,6 +44,9 @@ def parse():
                     help="compute all 77 positions of every caption as the reference does; default: the text tower runs on the "
                          "valid tokens only (rows behind <|endoftext|> never reach the loss; same logits and gradients)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra all-text-positions timing leg")
+    ap.add_argument("--overlap-adamw", action="store_true",
+                    help="per-block AdamW launches issued from inside backward instead of one launch in optimizer.step() "
+                         "(bit-identical; measured +-0 on one GPU: the chip is already full during backward)")
     ap.add_argument("--phase-times", action="store_true", help="diagnostic: GPU time between the phase boundaries of a step")
     ap.add_argument("--serial-towers", action="store_true",
                     help="run both towers on one stream (used for per-kernel profiles; the headline run overlaps them)")
@@ -202,6 +205,9 @@ def main():
                                                      amsgrad=False, eps=1e-8)))
     sched = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=opt, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                             warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
+    if args.overlap_adamw:
+        # reference order (zero_grad, one backward, step): each block's AdamW goes out as soon as its gradients are final
+        opt.overlap_backward(True)
     ddp.train()
     if os.environ.get("ILVLM_GEMM_VARIANT"):          # tuning hook (benchmarks): force one bf16 GEMM kernel
         ops.gemm_set_variant(int(os.environ["ILVLM_GEMM_VARIANT"]))
@@ -374,6 +380,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "towers": "serial" if args.serial_towers else "concurrent (one HIP stream per tower + a weight-gradient companion stream each)",
+            "optimizer": "fused AdamW, one launch in step()" if not args.overlap_adamw else
+                         "fused AdamW inside the timed step: per-block launches on their own stream as soon as a block's gradients are final, the rest in step()",
             "config": {"workload": "example/clip_fdt %s + FDT codebook (4096x512, sparsemax, max-pool, T=1000), "
                                    "%s compute / fp32 master weights, full train step incl. AdamW" % (
                                        "ViT-B/32" if args.model == "vitb32" else "ViT-L/14 (BASELINE configs[3])", args.precision),

@@ -13,25 +13,26 @@ constexpr int CHUNK = 4096;   // elements per workgroup-chunk (16 per thread)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow,
                                                     const int64_t* __restrict__ coff, const int32_t* __restrict__ ccnt,
-                                                    const int32_t* __restrict__ cgrp, ilvlm_adamw_hyper h, float bc1,
-                                                    float bc2_sqrt) {
-    const int ch = blockIdx.x;
-    const int grp = cgrp[ch];
-    if (!h.active[grp]) return;
-    const long off = coff[ch];
-    const int n = ccnt[ch];
-    const float lr = h.lr[grp], wd = h.weight_decay[grp];
-    const float decay = 1.f - lr * wd, step_size = lr / bc1;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const long k = off + i;
-        float gk = g[k], pk = p[k] * decay;
-        float mk = h.beta1 * m[k] + (1.f - h.beta1) * gk;
-        float vk = h.beta2 * v[k] + (1.f - h.beta2) * gk * gk;
-        m[k] = mk;
-        v[k] = vk;
-        pk -= step_size * mk / (sqrtf(vk) / bc2_sqrt + h.eps);
-        p[k] = pk;
-        if (shadow) shadow[k] = (bf16)pk;
+                                                    const int32_t* __restrict__ cgrp, int n_chunks, ilvlm_adamw_hyper h,
+                                                    float bc1, float bc2_sqrt) {
+    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int grp = cgrp[ch];
+        if (!h.active[grp]) continue;
+        const long off = coff[ch];
+        const int n = ccnt[ch];
+        const float lr = h.lr[grp], wd = h.weight_decay[grp];
+        const float decay = 1.f - lr * wd, step_size = lr / bc1;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const long k = off + i;
+            float gk = g[k], pk = p[k] * decay;
+            float mk = h.beta1 * m[k] + (1.f - h.beta1) * gk;
+            float vk = h.beta2 * v[k] + (1.f - h.beta2) * gk * gk;
+            m[k] = mk;
+            v[k] = vk;
+            pk -= step_size * mk / (sqrtf(vk) / bc2_sqrt + h.eps);
+            p[k] = pk;
+            if (shadow) shadow[k] = (bf16)pk;
+        }
     }
 }
 
@@ -46,7 +47,8 @@ extern "C" int ilvlm_adamw_step(float* params, const float* grads, float* exp_av
     const double bc1 = 1.0 - pow((double)hyper->beta1, (double)hyper->step);
     const double bc2 = 1.0 - pow((double)hyper->beta2, (double)hyper->step);
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                       (bf16*)shadow_bf16, chunk_offset, chunk_count, chunk_group, *hyper, (float)bc1, (float)sqrt(bc2));
+                       (bf16*)shadow_bf16, chunk_offset, chunk_count, chunk_group, n_chunks, *hyper, (float)bc1,
+                       (float)sqrt(bc2));
     ILVLM_LAUNCH_CHECK("adamw_step");
     return ILVLM_OK;
 }

@@ -53,6 +53,7 @@ class ParamArena:
         self.shadow_fresh = False # set by the fused optimizer: its kernel wrote the bf16 shadow of what it updated
         self._versions = None
         self.reducer = None       # comm.GradReducer installed by the data-parallel wrapper
+        self.eager_opt = None     # FusedAdamW.overlap_backward(): the optimizer that updates blocks from inside backward
         for n, p in self.named:
             o, k = self.offsets[n], p.numel()
             v = self.P[o:o + k].view(p.shape)
@@ -422,7 +423,8 @@ class Engine:
         wants each block's gradients final right away): every block's two LayerNorm backward launches leave their partial
         rows in their own slots, and ONE kernel adds all of them up at the end of the tower -- 1 launch instead of 24
         8 us launches on the dgrad chain.  Returns the slot tensor [n_blocks, 2, 2 * LN_WS_BLOCKS * E] or None."""
-        if not (self.defer_ln and self.composite and ops._gemm_profiler is None and self.arena.reducer is None):
+        if not (self.defer_ln and self.composite and ops._gemm_profiler is None and self.arena.reducer is None
+                and self.arena.eager_opt is None):
             return None
         key = (tower, n_blocks, E)
         st = self._ln_defer.get(key)

@@ -118,3 +118,7 @@ class ContrastiveBase(nn.Module):
     def _sync(self, what):
         if self._grad_sync is not None:
             self._grad_sync(what)
+        # optimizer.overlap_backward(): the block's update starts now, on the optimizer's stream
+        opt = getattr(self._eng.arena, "eager_opt", None)
+        if opt is not None and what.endswith("."):
+            opt.block_grads_final(what, self._eng._wg.get(torch.cuda.current_stream().cuda_stream))

@@ -301,6 +301,11 @@ class ClsSolver:
         kwargs = dict(oc.kwargs)
         kwargs["params"] = param_group_all(self.model, pconfig)[0]
         self.optimizer = optim_entry(dict(type=oc.type, kwargs=kwargs))
+        # train_step() below keeps the reference's order (zero_grad, one backward, step, nothing touching gradients in
+        # between), which is what the in-backward update needs
+        # (opt-in: on one GPU it measured +-0, the chip is already full during backward)
+        if os.environ.get("ILVLM_ADAMW_IN_BACKWARD", "0") == "1":
+            self.optimizer.overlap_backward(True)
         if "optimizer" in self.state and not self.fdt:
             # the baseline solver restores optimizer state (example/clip/train_solver.py:279-280); the FDT solver does not
             load_state_optimizer(self.optimizer, self.state["optimizer"])

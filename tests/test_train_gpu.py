@@ -338,3 +338,54 @@ def test_shadow_cast_is_skipped_only_when_the_optimizer_kept_it_current():
         assert len(casts) == 5                        # no optimizer step in between: cast again (nothing vouches for it)
     finally:
         ops.cast_f32 = real
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_adamw_issued_from_inside_backward_is_bit_identical(precision):
+    """optimizer.overlap_backward(): every transformer block is updated on the optimizer's stream as soon as its gradients are
+    final; step() takes the rest.  With the gradients of that very backward, the one-launch update gives the same bits."""
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    from ilvlm_amd.prototype.optimizer import optim_entry
+    from ilvlm_amd.prototype.utils.misc import param_group_all
+    c, v = CFG["a"], FDT_VARIANTS[0]
+    kw = model_kwargs(c, v)
+    kw["precision"] = precision
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=kw))
+    model.load_state_dict({k: torch.from_numpy(a) for k, a in det_state(state_shapes(c, True), 11).items()})
+    model.cuda().train()
+    opt = optim_entry(dict(type="AdamW", kwargs=dict(params=param_group_all(model, PCONFIG)[0], lr=1e-3, weight_decay=0.1,
+                                                     betas=[0.9, 0.98], amsgrad=False, eps=1e-8)))
+    opt.overlap_backward(True)
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 5)).cuda()
+    tok, mask = det_tokens(c["batch"], c["ctx"], 5)
+    texts = (torch.from_numpy(tok), torch.from_numpy(mask))
+    crit = ClipInfoCELoss()
+    n_blocks = len(model.visual.transformer.resblocks) + len(model.encode_text.transformer.resblocks)
+    for it in range(3):
+        (li, lt), _ = model(img, texts)
+        opt.zero_grad()
+        a = model.engine.arena
+        before = [t.clone() for t in (a.P, opt.M, opt.V)] if it else None
+        crit(li, lt)[0].backward()
+        if it:
+            assert len(opt._eager) == n_blocks            # every block went out during backward
+        grads = a.G.clone()
+        opt.step()
+        assert not opt._eager
+        if not it:
+            continue                                       # first step binds the arena (no state to snapshot before it)
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (a.P, opt.M, opt.V)] + ([a.S.clone()] if a.S is not None else [])
+        assert not torch.equal(got[0], before[0])
+        # the same update in one launch from the same state and gradients
+        a.P.copy_(before[0]); opt.M.copy_(before[1]); opt.V.copy_(before[2])
+        a.G.copy_(grads)
+        opt._step -= 1
+        opt.overlap_backward(False)
+        opt.step()
+        torch.cuda.synchronize()
+        want = [a.P, opt.M, opt.V] + ([a.S] if a.S is not None else [])
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+        opt.overlap_backward(True)
