@@ -95,7 +95,8 @@ typedef struct ilvlm_gemm_epilogue {
     const float* alpha_ptr2; /* second device scalar multiplied into alpha (fp8: the two de-quantisation scales) or NULL */
     /* fp8 copy of the stored output for the next fp8 GEMM (fp8 mode): out8[m, n] (bytes, same ldc) = fp8(value * out8_scale[0])
      * in e4m3 (out8_fmt 0) or e5m2 (1); out8_amax[0] is raised to max|value| (either may be NULL).  Direct-to-LDS bf16 /
-     * fp8 kernels only, not with accumulate or the pool epilogue, out_group == 0. */
+     * fp8 kernels only, not with accumulate or the pool epilogue, out_group == 0.  With out8 given, C may be NULL: only the
+     * copy (and aux) is kept -- the bf16 tensor would be written for nobody when every consumer reads the fp8 copy. */
     void* out8;
     const float* out8_scale;
     float* out8_amax;
@@ -261,7 +262,8 @@ int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream);
 
 /* ---- fused multi-tensor AdamW (torch.optim.AdamW semantics, optimizer/__init__.py:3,18-26).
  * The parameters live in one flat fp32 arena; `chunk_*` arrays (device) describe n_chunks pieces:
- * element offset, element count and param-group id of each; lr/wd are per group (<= 16 groups).
+ * element offset (a multiple of 4: the kernel moves 16 bytes per lane), element count and param-group id of each; lr/wd
+ * are per group (<= 16 groups).
  * active[group] == 0 skips the group entirely (parameters without gradient are not touched).
  * shadow (optional, bf16) receives the updated parameters. step is 1-based. */
 typedef struct ilvlm_adamw_hyper {
@@ -318,7 +320,8 @@ int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, 
                     float* din_f32, void* din_lp, void* scratch, float* ln_ws, int ln_ws_blocks, long rows, int B, int L,
                     int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream, const void* dx8,
                     void* din8, const float* din8_scale, float* din8_amax);
-/* fp8 mode (b->fp8 == 2), all four nullable: dx8 = e5m2 copy of dx_lp if the producer already made one (the previous call's
+/* fp8 mode (b->fp8 >= 2), all four nullable.  With b->fp8 == 3 and all four weight gradients requested, dx_lp may be NULL
+ * when dx8 is given and din_lp may be NULL when din8 is given (every consumer then reads the e5m2 copy): dx8 = e5m2 copy of dx_lp if the producer already made one (the previous call's
  * din8), else the call quantises dx_lp itself; din8 [rows, E] bytes receives the e5m2 copy of din_lp, quantised with
  * din8_scale[0] (the d(x_out) slot of the block that will consume it), din8_amax[0] raised to max|din_lp|. */
 
@@ -337,6 +340,15 @@ int ilvlm_attention_packed_fwd(const void* qkv, void* out, float* lse, int dtype
                                const int32_t* seq_offs, void* stream);
 int ilvlm_attention_packed_bwd(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype,
                                int B, int L, int Lcap, int H, int causal, const int32_t* seq_offs, void* stream);
+/* fp8 mode: the same kernels also emit the fp8 copy their consumer GEMM reads and raise q_amax[0] to max|value| (the copy
+ * quantises the bf16-rounded value with q_scale[0]; out8 / dqkv8 NULL = observe the amax only).  Forward: out8 [rows, E]
+ * e4m3 of `out`.  Backward: dqkv8 [rows, 3E] e5m2 of `dqkv`; dqkv itself may be NULL when every consumer reads the copy;
+ * sequences up to 128 tokens.  bf16 only.  seq_offs NULL = dense rows (Lcap ignored). */
+int ilvlm_attention_fwd_q8(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
+                           const int32_t* seq_offs, void* out8, const float* q_scale, float* q_amax, void* stream);
+int ilvlm_attention_bwd_q8(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype, int B,
+                           int L, int Lcap, int H, int causal, const int32_t* seq_offs, void* dqkv8, const float* q_scale,
+                           float* q_amax, void* stream);
 /* idx[b] = position inside sequence b (EOT pooling, text_transformer.py:248) */
 int ilvlm_gather_packed_rows(const float* x, const int64_t* idx, const int32_t* seq_offs, float* y, int B, int W, void* stream);
 int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, const int32_t* seq_offs, float* dx, int B, int W,

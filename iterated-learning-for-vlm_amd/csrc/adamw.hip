@@ -22,7 +22,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const int n = ccnt[ch];
         const float lr = h.lr[grp], wd = h.weight_decay[grp];
         const float decay = 1.f - lr * wd, step_size = lr / bc1;
-        for (int i = threadIdx.x; i < n; i += 256) {
+        // chunk offsets are multiples of 64 elements: 16-byte accesses, four elements per lane, then the tail
+        const int n4 = n & ~3;
+        for (int i = threadIdx.x * 4; i < n4; i += 1024) {
+            const long k = off + i;
+            const f32x4 gk = *(const f32x4*)(g + k);
+            f32x4 pk = *(const f32x4*)(p + k), mk = *(const f32x4*)(m + k), vk = *(const f32x4*)(v + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pk[j] *= decay;
+                mk[j] = h.beta1 * mk[j] + (1.f - h.beta1) * gk[j];
+                vk[j] = h.beta2 * vk[j] + (1.f - h.beta2) * gk[j] * gk[j];
+                pk[j] -= step_size * mk[j] / (sqrtf(vk[j]) / bc2_sqrt + h.eps);
+            }
+            *(f32x4*)(m + k) = mk;
+            *(f32x4*)(v + k) = vk;
+            *(f32x4*)(p + k) = pk;
+            if (shadow) store4<bf16>(shadow + k, pk);
+        }
+        for (int i = n4 + threadIdx.x; i < n; i += 256) {
             const long k = off + i;
             float gk = g[k], pk = p[k] * decay;
             float mk = h.beta1 * m[k] + (1.f - h.beta1) * gk;

@@ -65,6 +65,21 @@ __device__ __forceinline__ float group4_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// fp8 copy of a kernel's bf16 output for the fp8 GEMM that consumes it (fp8 mode: saves the separate quantise pass over
+// the tensor).  out8 has the layout of the bf16 output; amax is raised to max|value| (non-null = the feature is on; out8 may
+// still be null: observe only).  The copy quantises the bf16-rounded value, exactly what the separate pass would read.
+struct AttnQ8 {
+    unsigned char* out8;
+    const float* scale;
+    float* amax;
+};
+template <int FMT>
+__device__ __forceinline__ void q8_emit(unsigned char* out8, long off, bf16x4 v, float qs, float& qm) {
+    const float a = (float)v[0], b = (float)v[1], c = (float)v[2], d = (float)v[3];
+    qm = fmaxf(qm, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
+    if (out8) *(unsigned*)(out8 + off) = fp8_pack4<FMT>(a * qs, b * qs, c * qs, d * qs);
+}
+
 // [rows < L][64] slice of the packed rows -> [ROWS][72] LDS image, zero padded; NTH threads
 template <int ROWS, int NTH>
 __device__ __forceinline__ void stage_rows(bf16* dst, const bf16* src, long row_stride, int L, float scale, int tid) {
@@ -93,9 +108,11 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16* src, long row_stride, 
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_wave(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                          float* __restrict__ lse, int Lmax, int H, int causal,
-                                                         const int* __restrict__ seq_offs) {
+                                                         const int* __restrict__ seq_offs, AttnQ8 q8) {
     constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const float qs = q8.out8 ? q8.scale[0] : 1.f;
+    float qm = 0.f;
     bf16* Ks = (bf16*)smem_raw;          // [ROWS][72]
     bf16* Vs = Ks + ROWS * LDH;          // [ROWS][72]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,9 +196,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_wave(const bf16* __restrict_
                                                             pack8(pk[2 * kp], pk[2 * kp + 1]), o, 0, 0, 0);
         if (q < L) {
             bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-            *(bf16x4*)(out + (row0 + q) * E + h * HD + dt * 16 + 4 * g) = ov;
+            const long off = (row0 + q) * E + h * HD + dt * 16 + 4 * g;
+            *(bf16x4*)(out + off) = ov;
+            if (q8.amax) q8_emit<0>(q8.out8, off, ov, qs, qm);
         }
     }
+    }
+    if (q8.amax) {                 // every wave reaches this point (the tile loop only breaks wave-uniformly)
+        qm = wave_max(qm);
+        if (lane == 0) fp8_amax_raise(q8.amax, qm);
     }
 }
 
@@ -189,9 +212,11 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
                                                          const bf16* __restrict__ outp, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, int Lmax, int H, int causal,
-                                                         const int* __restrict__ seq_offs) {
+                                                         const int* __restrict__ seq_offs, AttnQ8 q8) {
     constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const float qs = q8.out8 ? q8.scale[0] : 1.f;      // e5m2 copy of dqkv (dqkv itself may then be null)
+    float qm = 0.f;
     bf16* Qs = (bf16*)smem_raw;          // [ROWS][72], pre-scaled by 1/8
     bf16* Ks = Qs + ROWS * LDH;
     bf16* dOs = Ks + ROWS * LDH;
@@ -284,7 +309,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict_
                                                                   pack8(ds[2 * kp], ds[2 * kp + 1]), acc, 0, 0, 0);
             if (q < L) {
                 bf16x4 ov = {(bf16)(acc[0] * 0.125f), (bf16)(acc[1] * 0.125f), (bf16)(acc[2] * 0.125f), (bf16)(acc[3] * 0.125f)};
-                *(bf16x4*)(dqkv + (row0 + q) * rs + h * HD + dt * 16 + 4 * g) = ov;
+                const long off = (row0 + q) * rs + h * HD + dt * 16 + 4 * g;
+                if (dqkv) *(bf16x4*)(dqkv + off) = ov;
+                if (q8.amax) q8_emit<1>(q8.out8, off, ov, qs, qm);
             }
         }
     }
@@ -344,11 +371,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict_
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 kv = {(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
                 bf16x4 vv = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
-                bf16* o = dqkv + (row0 + key) * rs + h * HD + dt * 16 + 4 * g;
-                *(bf16x4*)(o + E) = kv;
-                *(bf16x4*)(o + 2 * E) = vv;
+                const long off = (row0 + key) * rs + h * HD + dt * 16 + 4 * g;
+                if (dqkv) {
+                    *(bf16x4*)(dqkv + off + E) = kv;
+                    *(bf16x4*)(dqkv + off + 2 * E) = vv;
+                }
+                if (q8.amax) {
+                    q8_emit<1>(q8.out8, off + E, kv, qs, qm);
+                    q8_emit<1>(q8.out8, off + 2 * E, vv, qs, qm);
+                }
             }
         }
+    }
+    if (q8.amax) {
+        qm = wave_max(qm);
+        if (lane == 0) fp8_amax_raise(q8.amax, qm);
     }
 }
 
@@ -728,7 +765,7 @@ int set_lds(K kern, int bytes, const char* name) {
 
 template <int NT, int NW = NT>
 int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H, int causal, const int* seq_offs,
-                    hipStream_t s) {
+                    hipStream_t s, AttnQ8 q8) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 2 * ROWS * LDH * 2;
     if (bytes > 64 * 1024) {
@@ -739,13 +776,13 @@ int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H,
             done = true;
         }
     }
-    hipLaunchKernelGGL((attn_fwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, qkv, out, lse, L, H, causal, seq_offs);
+    hipLaunchKernelGGL((attn_fwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, qkv, out, lse, L, H, causal, seq_offs, q8);
     ILVLM_LAUNCH_CHECK("attention_fwd");
     return ILVLM_OK;
 }
 template <int NT, int NW = NT>
 int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
-                    int causal, const int* seq_offs, hipStream_t s) {
+                    int causal, const int* seq_offs, hipStream_t s, AttnQ8 q8) {
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // 57 KB at 128 tokens, 127 KB at 288
     if (bytes > 64 * 1024) {
@@ -757,7 +794,7 @@ int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const fl
         }
     }
     hipLaunchKernelGGL((attn_bwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal,
-                       seq_offs);
+                       seq_offs, q8);
     ILVLM_LAUNCH_CHECK("attention_bwd");
     return ILVLM_OK;
 }
@@ -782,8 +819,9 @@ int launch_bwd_tiled_bf16(const bf16* dout, const bf16* qkv, const bf16* out, co
 // Lcap: longest sequence of the launch (tile count / LDS size); L: row stride of lse and, for the dense layout
 // (seq_offs == nullptr), the length of every sequence
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
-                              const int* seq_offs, void* stream) {
+                              const int* seq_offs, void* stream, AttnQ8 q8 = AttnQ8{nullptr, nullptr, nullptr}) {
     ILVLM_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
+    ILVLM_REQUIRE(!q8.amax || (dtype == ILVLM_BF16 && (!q8.out8 || q8.scale)), "attention_fwd: the fp8 copy needs bf16 and a scale");
     ILVLM_REQUIRE(B > 0 && L > 0 && H > 0 && Lcap > 0 && Lcap <= L, "attention_fwd: bad shape B=%d L=%d Lcap=%d H=%d", B, L, Lcap, H);
     ILVLM_REQUIRE(!seq_offs || Lcap <= (dtype == ILVLM_BF16 ? 128 : 96), "attention_fwd: packed rows support sequences up to 128 (bf16) / 96 (f32) tokens");
     hipStream_t s = (hipStream_t)stream;
@@ -792,19 +830,19 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype,
         const bf16* q = (const bf16*)qkv;
         bf16* o = (bf16*)out;
         switch ((Lcap + 15) / 16) {
-            case 1: return launch_fwd_wave<1>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 2: return launch_fwd_wave<2>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 3: return launch_fwd_wave<3>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 4: return launch_fwd_wave<4>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 5: return launch_fwd_wave<5>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 9: case 10: return launch_fwd_wave<10, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 11: case 12: return launch_fwd_wave<12, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 13: case 14: return launch_fwd_wave<14, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 15: case 16: return launch_fwd_wave<16, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
-            case 17: case 18: return launch_fwd_wave<18, 8>(q, o, lse, B, L, H, causal, seq_offs, s);
+            case 1: return launch_fwd_wave<1>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 2: return launch_fwd_wave<2>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 3: return launch_fwd_wave<3>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 4: return launch_fwd_wave<4>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 5: return launch_fwd_wave<5>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 6: return launch_fwd_wave<6>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 7: return launch_fwd_wave<7>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 8: return launch_fwd_wave<8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 9: case 10: return launch_fwd_wave<10, 8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 11: case 12: return launch_fwd_wave<12, 8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 13: case 14: return launch_fwd_wave<14, 8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 15: case 16: return launch_fwd_wave<16, 8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
+            case 17: case 18: return launch_fwd_wave<18, 8>(q, o, lse, B, L, H, causal, seq_offs, s, q8);
             default: break;
         }
         ILVLM_FAIL(ILVLM_ERR_ARG, "attention_fwd(bf16): no kernel for L=%d", L);
@@ -839,8 +877,11 @@ extern "C" int ilvlm_attention_packed_fwd(const void* qkv, void* out, float* lse
 }
 
 static int attention_bwd_impl(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype,
-                              int B, int L, int Lcap, int H, int causal, const int* seq_offs, void* stream) {
-    ILVLM_REQUIRE(dout && qkv && out && lse && dqkv, "attention_bwd: null pointer");
+                              int B, int L, int Lcap, int H, int causal, const int* seq_offs, void* stream,
+                              AttnQ8 q8 = AttnQ8{nullptr, nullptr, nullptr}) {
+    ILVLM_REQUIRE(dout && qkv && out && lse && (dqkv || q8.out8), "attention_bwd: null pointer");
+    ILVLM_REQUIRE(!q8.amax || (dtype == ILVLM_BF16 && Lcap <= 128 && (!q8.out8 || q8.scale)),
+                  "attention_bwd: the fp8 copy needs bf16, a scale and sequences up to 128 tokens (wave-per-tile kernel)");
     ILVLM_REQUIRE(B > 0 && L > 0 && H > 0 && Lcap > 0 && Lcap <= L, "attention_bwd: bad shape B=%d L=%d Lcap=%d H=%d", B, L, Lcap, H);
     ILVLM_REQUIRE(!seq_offs || Lcap <= (dtype == ILVLM_BF16 ? 128 : 80), "attention_bwd: packed rows support sequences up to 128 (bf16) / 80 (f32) tokens");
     hipStream_t s = (hipStream_t)stream;
@@ -849,14 +890,14 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
         const bf16 *d = (const bf16*)dout, *q = (const bf16*)qkv, *o = (const bf16*)out;
         bf16* dq = (bf16*)dqkv;
         switch ((Lcap + 15) / 16) {
-            case 1: return launch_bwd_wave<1>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 2: return launch_bwd_wave<2>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 3: return launch_bwd_wave<3>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 4: return launch_bwd_wave<4>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 5: return launch_bwd_wave<5>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
-            case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s);
+            case 1: return launch_bwd_wave<1>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 2: return launch_bwd_wave<2>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 3: return launch_bwd_wave<3>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 4: return launch_bwd_wave<4>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 5: return launch_bwd_wave<5>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 6: return launch_bwd_wave<6>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 7: return launch_bwd_wave<7>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
+            case 8: return launch_bwd_wave<8>(d, q, o, lse, dq, B, L, H, causal, seq_offs, s, q8);
             // longer sequences: the wave-per-tile backward would hold 14-18 tiles of dS per wave and spills at 256 VGPRs
             // (425 us against 325 us for the key-block kernel below at L = 257); the forward does profit (190 -> 117 us)
             default: break;
@@ -894,4 +935,22 @@ extern "C" int ilvlm_attention_packed_bwd(const void* dout, const void* qkv, con
                                           void* stream) {
     ILVLM_REQUIRE(seq_offs, "attention_packed_bwd: null seq_offs");
     return attention_bwd_impl(dout, qkv, out, lse, dqkv, dtype, B, L, Lcap, H, causal, seq_offs, stream);
+}
+
+// fp8 mode: the attention kernels also emit the fp8 copy their consumer GEMM reads (forward: e4m3 of `out` for the output
+// projection; backward: e5m2 of `dqkv` for the in-projection's input / weight gradients) and raise the slot's amax, saving a
+// quantise pass over the tensor.  seq_offs nullable (dense rows, then Lcap = L).  Backward: dqkv may be NULL when only the fp8
+// copy is consumed; sequences up to 128 tokens.
+extern "C" int ilvlm_attention_fwd_q8(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
+                                      const int32_t* seq_offs, void* out8, const float* q_scale, float* q_amax, void* stream) {
+    ILVLM_REQUIRE(q_amax, "attention_fwd_q8: null amax");
+    return attention_fwd_impl(qkv, out, lse, dtype, B, L, seq_offs ? Lcap : L, H, causal, seq_offs, stream,
+                              AttnQ8{(unsigned char*)out8, q_scale, q_amax});
+}
+extern "C" int ilvlm_attention_bwd_q8(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype,
+                                      int B, int L, int Lcap, int H, int causal, const int32_t* seq_offs, void* dqkv8,
+                                      const float* q_scale, float* q_amax, void* stream) {
+    ILVLM_REQUIRE(q_amax, "attention_bwd_q8: null amax");
+    return attention_bwd_impl(dout, qkv, out, lse, dqkv, dtype, B, L, seq_offs ? Lcap : L, H, causal, seq_offs, stream,
+                              AttnQ8{(unsigned char*)dqkv8, q_scale, q_amax});
 }

@@ -97,6 +97,13 @@ int wgrad_split(long out_rows, long out_cols, long k, int tile, int target) {
         if (rc__) return rc__; \
     } while (0)
 
+// fp8 == 3 with all four weight matrices trainable: forward, input-gradient and weight-gradient GEMMs all read fp8 copies,
+// and the bf16 tensors nobody else reads are not written (a frozen weight keeps the fp8 == 2 behaviour for the whole block:
+// its bias gradient is a column sum over the bf16 gradient)
+inline bool fp8_all(const ilvlm_block* b) {
+    return b->fp8 == 3 && b->g_in_w && b->g_out_w && b->g_fc_w && b->g_proj_w;
+}
+
 enum { F8_H1 = 0, F8_ATT, F8_H2, F8_G, F8_IN_W, F8_OUT_W, F8_FC_W, F8_PROJ_W, F8_DOUT, F8_DU, F8_DMID, F8_DQKV };
 
 // fp8 copy of x (n elements) for slot `slot`; fp8 == 1 only records the amax.  Returns the quantised buffer or null.
@@ -203,11 +210,14 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     // fp8 mode: the fp8 copy of each GEMM input is emitted by its producer where that is a kernel of this library with the
     // values in registers (LayerNorm, the fc GEMM's QuickGELU epilogue); the attention output takes a quantise pass
     hipStream_t s = (hipStream_t)stream;
-    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0;
+    // fp8 == 3 (weight gradients on fp8 operands too): every consumer of ln_1 / ln_2's output and of the activation g reads
+    // the e4m3 copy, so the bf16 tensors are not written at all
+    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0, f8only = fp8_all(b);
     void *h1_8 = w + o.h1_8, *att8 = w + o.att8, *h2_8 = w + o.h2_8, *g8 = w + o.g8;
     const float* sc = b->f8_scale;
     float* am = b->f8_amax;
     const void* x8;
+    if (f8only) h1 = h2 = g = nullptr;
     TRY(ilvlm_layernorm_fwd_q8(x_in, ILVLM_F32, b->ln1_w, b->ln1_b, h1, T, mean1, rstd1, rows, E, 1e-5f, 0, 0, f8on ? h1_8 : nullptr,
                                f8on ? sc + F8_H1 : nullptr, f8obs ? am + F8_H1 : nullptr, stream));
     ilvlm_gemm_epilogue ep = {};
@@ -215,9 +225,14 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.out_dtype = T;
     ep.bias = b->in_b;
     TRY(linear_fwd(b, h1, f8on ? h1_8 : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s));
-    if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
-    else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
-    TRY(f8_quant(b, att, rows * E, F8_ATT, 0, att8, s, &x8));
+    if (f8on) {                  // the attention kernel emits the e4m3 copy of its output itself
+        TRY(ilvlm_attention_fwd_q8(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, att8, sc + F8_ATT, am + F8_ATT, stream));
+        x8 = att8;
+    } else {
+        if (seq_offs) TRY(ilvlm_attention_packed_fwd(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, stream));
+        else TRY(ilvlm_attention_fwd(qkv, att, lse, T, B, L, b->H, b->causal, stream));
+        TRY(f8_quant(b, att, rows * E, F8_ATT, 0, att8, s, &x8));
+    }
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
@@ -257,7 +272,8 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     ILVLM_REQUIRE(x_in && saved && dx_f32 && din_f32 && scratch && rows > 0 && B > 0 && L > 0, "block_bwd: bad arguments");
     const int E = b->E, T = b->dtype;
     const bool lp = T != ILVLM_F32;
-    ILVLM_REQUIRE(!lp || (dx_lp && din_lp), "block_bwd: the low-precision gradient copies are required in bf16 mode");
+    ILVLM_REQUIRE(!lp || ((dx_lp || (dx8 && fp8_all(b))) && (din_lp || (din8 && fp8_all(b)))),
+                  "block_bwd: the low-precision gradient copies are required in bf16 mode (fp8 == 3: or their e5m2 copies)");
     ILVLM_REQUIRE(wgrad_target > 0, "block_bwd: wgrad_target must be positive");
     const Saved o(b, rows, B, L);
     const Scratch c(b, rows);
@@ -269,6 +285,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
                 *lse = (const float*)(w + o.lse), *x_mid = (const float*)(w + o.x_mid);
     const void *h1 = w + o.h1, *qkv = w + o.qkv, *att = w + o.att, *h2 = w + o.h2, *u = w + o.u, *g = w + o.g;
     void *du = t + c.du, *dh2 = t + c.dh2, *da = t + c.da, *dqkv = t + c.dqkv, *dh1 = t + c.dh1;
+    const int Lq = seq_offs ? Lcap : L;            // longest sequence of the launch
     float* dmid = (float*)(t + c.dmid);
     void* dmid_lp = lp ? (void*)(t + c.dmid_lp) : nullptr;
     // deferred LayerNorm reductions: slot 0 = ln_2, slot 1 = ln_1 (each 2 * |ln_ws_blocks| * E floats)
@@ -280,7 +297,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // out of ln_2's backward, dqkv takes a quantise pass; ln_1's backward emits the next call's d(x_out) into din8.
     // fp8 == 3: the four weight gradients take fp8 operands as well (the e5m2 gradient copies x the e4m3 activation copies
     // kept by the forward pass)
-    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0, f8wg = b->fp8 == 3;
+    const bool f8on = b->fp8 >= 2, f8obs = b->fp8 != 0, f8wg = fp8_all(b);
     void *dout8 = t + c.dout8, *du8 = t + c.du8, *dmid8 = t + c.dmid8, *dqkv8 = t + c.dqkv8;
     const void *h1_8 = f8wg ? w + o.h1_8 : nullptr, *att8 = f8wg ? w + o.att8 : nullptr, *h2_8 = f8wg ? w + o.h2_8 : nullptr,
                *g8a = f8wg ? w + o.g8 : nullptr;
@@ -292,6 +309,9 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     ILVLM_REQUIRE(!din8 || din8_scale, "block_bwd: din8 needs its scale");
     if (dx8) g8 = dx8;
     else TRY(f8_quant(b, dy, rows * E, F8_DOUT, 1, dout8, s, &g8));
+    // with fp8 weight gradients every consumer of du, d(x_mid)'s bf16 copy, dqkv and (when the caller takes din8) din_lp reads
+    // the e5m2 copy: the bf16 tensors are not written
+    if (f8wg) du = nullptr;
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
                    g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,
@@ -299,6 +319,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
+    if (f8wg) dmid_lp = nullptr;
     TRY(ilvlm_layernorm_bwd_q8(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
                                b->g_ln2_b, rows, E, 0, 0, ln_ws, ln_ws_blocks, f8on ? dmid8 : nullptr, f8on ? sc + F8_DMID : nullptr,
                                f8obs ? am + F8_DMID : nullptr, s));
@@ -306,11 +327,19 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
     TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT));
-    if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
-    else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
-    TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, dqkv8, s, &g8));
+    if (f8on && Lq <= 128) {     // the wave-per-tile backward emits the e5m2 copy of dqkv itself
+        if (f8wg) dqkv = nullptr;
+        TRY(ilvlm_attention_bwd_q8(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, dqkv8, sc + F8_DQKV,
+                                   am + F8_DQKV, s));
+        g8 = dqkv8;
+    } else {
+        if (seq_offs) TRY(ilvlm_attention_packed_bwd(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, s));
+        else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
+        TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, dqkv8, s, &g8));
+    }
     TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
                    inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1));
-    return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32, lp ? din_lp : nullptr, T, 0,
+    return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32,
+                                  lp ? din_lp : nullptr, T, 0,
                                   nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, din8, din8_scale, din8_amax, s);
 }

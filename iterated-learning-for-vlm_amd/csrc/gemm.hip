@@ -70,7 +70,8 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
             }
         }
         if (e.residual) v += *(const f32x4*)(e.residual + off);
-        if (e.out_dtype == ILVLM_F32) store4<float>(a.Cf + off, v);
+        if (!a.Cf) {}                      // only the fp8 copy (and aux) of the result is kept
+        else if (e.out_dtype == ILVLM_F32) store4<float>(a.Cf + off, v);
         else store4<bf16>(a.Cb + off, v);
         if (amax8) out8_store(e, off, v, 4, *amax8);
         return;
@@ -90,7 +91,8 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
             else x *= gelu_erf_grad(to_f<AuxT>(*aux));
         }
         if (e.residual) x += e.residual[off + i];
-        if (e.out_dtype == ILVLM_F32) a.Cf[off + i] = x;
+        if (!a.Cf) {}
+        else if (e.out_dtype == ILVLM_F32) a.Cf[off + i] = x;
         else a.Cb[off + i] = (bf16)x;
         fin[i] = x;
     }
@@ -552,7 +554,8 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
                             v[q] *= MODE == EPI_QGELU_BWD ? quick_gelu_grad(pre[k][q]) : gelu_erf_grad(pre[k][q]);
                     }
                     if constexpr (MODE == EPI_RES) v += pre[k];
-                    if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
+                    if (!ep.Cf) {}
+                    else if (e.out_dtype == ILVLM_F32) store4<float>(ep.Cf + off[k], v);
                     else store4<bf16>(ep.Cb + off[k], v);
                     if (e.out8 || e.out8_amax) out8_store(e, off[k], v, 4, amax8);
                 }
@@ -1255,7 +1258,11 @@ std::atomic<int> g_gemm_variant{5};
 extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                           const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k,
                           void* stream) {
-    ILVLM_REQUIRE(A && B && C && epi, "gemm: null pointer");
+    ILVLM_REQUIRE(A && B && epi, "gemm: null pointer");
+    // C == NULL: the result is kept only as its fp8 copy (out8; plus aux for the activation epilogues) -- fp8 mode, where
+    // the consumer GEMMs read the copy and the bf16 tensor would be written for nobody
+    ILVLM_REQUIRE(C || (epi->out8 && !epi->accumulate && !epi->pool_out && compute_dtype != ILVLM_F32),
+                  "gemm: null output (allowed only together with an fp8 output copy)");
     ILVLM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     ILVLM_REQUIRE(compute_dtype == ILVLM_F32 || compute_dtype == ILVLM_BF16 || compute_dtype == ILVLM_FP8 ||
                       compute_dtype == ILVLM_FP8_BF8A, "gemm: bad compute dtype %d", compute_dtype);

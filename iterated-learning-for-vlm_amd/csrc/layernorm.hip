@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c), o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
-            store4<TY>(yr + c, o);
+            if (y) store4<TY>(yr + c, o);
             if (q_amax) qm = fmaxf(qm, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             if (y8) *(unsigned*)(y8 + row * (long)cols + c) = fp8_pack4<0>(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
         }
@@ -121,14 +121,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                 for (int j = 0; j < 4; ++j) o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
                 if (dres) o += *(const f32x4*)(dres + srow * (long)cols + c);
                 if (dx_f32) *(f32x4*)(dx_f32 + srow * (long)cols + c) = o;
-                if (dx_lp) {
+                if (dx_lp || dx8 || q_amax) {      // the low-precision gradient; with dx8 alone only its fp8 copy is kept
                     if (act) {
                         f32x4 u = load4<TLP>(act_aux + row * (long)cols + c);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             o[j] *= act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
                     }
-                    store4<TLP>(dx_lp + srow * (long)cols + c, o);
+                    if (dx_lp) store4<TLP>(dx_lp + srow * (long)cols + c, o);
                     if (q_amax) qm = fmaxf(qm, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                     if (dx8) *(unsigned*)(dx8 + srow * (long)cols + c) = fp8_pack4<1>(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
                 }
@@ -240,7 +240,7 @@ extern "C" int ilvlm_layernorm_fwd_q8(const void* x, int x_dtype, const float* g
                                       float* mean, float* rstd, long rows, int cols, float eps, int in_group, int in_skip,
                                       void* y8, const float* q_scale, float* q_amax, void* stream) {
     ILVLM_REQUIRE(!y8 || (q_scale && in_group == 0), "layernorm_fwd_q8: the fp8 copy needs a scale and compact rows");
-    ILVLM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    ILVLM_REQUIRE(x && gamma && beta && (y || y8) && mean && rstd, "layernorm_fwd: null pointer");
     ILVLM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXV * 256, "layernorm_fwd: cols=%d must be a multiple of 4 and <= %d",
                   cols, MAXV * 256);
     hipStream_t s = (hipStream_t)stream;
@@ -275,10 +275,11 @@ extern "C" int ilvlm_layernorm_bwd_q8(const void* dy, int dy_dtype, const void* 
                                       int dx_lp_dtype, int act, const void* act_aux, float* dgamma, float* dbeta, long rows,
                                       int cols, int group, int skip, float* ws, int ws_blocks, void* dx8, const float* q_scale,
                                       float* q_amax, void* stream) {
-    ILVLM_REQUIRE(!(dx8 || q_amax) || (dx_lp && group == 0 && (!dx8 || q_scale)),
-                  "layernorm_bwd_q8: the fp8 copy follows the low-precision gradient (dx_lp), compact rows, with a scale");
+    ILVLM_REQUIRE(!(dx8 || q_amax) || (group == 0 && (!dx8 || q_scale)),
+                  "layernorm_bwd_q8: the fp8 copy needs compact rows and a scale");
+    ILVLM_REQUIRE(dx_lp || !act, "layernorm_bwd_q8: an activation derivative needs dx_lp");
     ILVLM_REQUIRE(dy && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
-    ILVLM_REQUIRE(dx_f32 || dx_lp, "layernorm_bwd: no output requested");
+    ILVLM_REQUIRE(dx_f32 || dx_lp || dx8, "layernorm_bwd: no output requested");
     ILVLM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXV * 256, "layernorm_bwd: bad cols %d", cols);
     ILVLM_REQUIRE(act == 0 || ((act == ILVLM_ACT_QUICKGELU_BWD || act == ILVLM_ACT_GELU_ERF_BWD) && act_aux && dx_lp),
                   "layernorm_bwd: bad activation arguments");

@@ -95,6 +95,12 @@ class ParamArena:
     def zero_grad(self):
         self.G.zero_()
 
+    def reducing(self):
+        """True when a data-parallel wrapper exchanges gradients over ranks in this process (a world of one rank does not,
+        unless comm.force_collectives is set): only then must each block's gradients be final as soon as its backward ends"""
+        from . import comm
+        return self.reducer is not None and comm._active(self.reducer.W)
+
     def wait_grads(self):
         """Order the current stream after any in-flight gradient all-reduce."""
         if self.reducer is not None:
@@ -220,6 +226,7 @@ class Engine:
         self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
         self.defer_ln = os.environ.get("ILVLM_DEFER_LN", "1") == "1"      # one LayerNorm-gradient reduction per tower
         self._f8_carry = None
+        self.join_each_block = os.environ.get("ILVLM_JOIN_EACH_BLOCK", "0") == "1"
         # fp8 mode: weight gradients on fp8 operands as well (e5m2 gradient copies x the e4m3 activation copies of the forward)
         self.fp8_wgrad = os.environ.get("ILVLM_FP8_WGRAD", "1") == "1"
         self._ln_defer = {}
@@ -423,7 +430,7 @@ class Engine:
         wants each block's gradients final right away): every block's two LayerNorm backward launches leave their partial
         rows in their own slots, and ONE kernel adds all of them up at the end of the tower -- 1 launch instead of 24
         8 us launches on the dgrad chain.  Returns the slot tensor [n_blocks, 2, 2 * LN_WS_BLOCKS * E] or None."""
-        if not (self.defer_ln and self.composite and ops._gemm_profiler is None and self.arena.reducer is None
+        if not (self.defer_ln and self.composite and ops._gemm_profiler is None and not self.arena.reducing()
                 and self.arena.eager_opt is None):
             return None
         key = (tower, n_blocks, E)
@@ -454,7 +461,14 @@ class Engine:
             desc = self._block_desc(pre, E, H, causal)
             lp = self.T != torch.float32
             din = _empty((M, E), torch.float32, x_in)
-            din_lp = _empty((M, E), self.T, x_in) if lp else None
+            f8 = self.fp8 if (self.fp8 is not None and self.fp8.active) else None
+            # fp8 weight gradients on: a consumer block whose four weight matrices are trainable reads only the e5m2 copy of
+            # this call's input gradient, so the bf16 copy is not produced
+            only8 = (f8 is not None and self.fp8_wgrad and f8_next is not None
+                     and all(self.req[f8_next + n] for n in Fp8State.WNAME.values())
+                     and all(self.req[pre + n] for n in Fp8State.WNAME.values())
+                     and self._block_desc(f8_next, E, H, causal) is not None)
+            din_lp = _empty((M, E), self.T, x_in) if (lp and not only8) else None
             scratch = torch.empty(ops.block_scratch_bytes(desc, M), dtype=torch.uint8, device=x_in.device)
             wg = self._wgrad_stream()
             if wg is not None:    # the scratch holds the dY operands of the weight-gradient GEMMs: alive until the join
@@ -547,7 +561,7 @@ class Engine:
                                            cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None, f8_in=carry,
                                            f8_next=("visual.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
             carry = self._f8_carry
-            if self.arena.reducer is not None:
+            if self.arena.reducing() or self.join_each_block:
                 self.join_wgrad()
             self.m._sync("visual.transformer.resblocks.%d." % i)       # this block's gradients are complete
         if st is not None:
@@ -631,7 +645,7 @@ class Engine:
                                            f8_in=carry,
                                            f8_next=("encode_text.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
             carry = self._f8_carry
-            if self.arena.reducer is not None:
+            if self.arena.reducing() or self.join_each_block:
                 self.join_wgrad()
             self.m._sync("encode_text.transformer.resblocks.%d." % i)
         if st is not None:

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ilvlm_embed_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_attention_packed_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "ilvlm_attention_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "ilvlm_attention_fwd_q8": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "ilvlm_attention_bwd_q8": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "ilvlm_gather_packed_rows": [vp, vp, vp, vp, i32, i32, vp],
     "ilvlm_scatter_packed_rows": [vp, vp, vp, vp, i32, i32, vp],
     "ilvlm_fdt_pool_packed_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp],

@@ -269,3 +269,69 @@ def test_fused_fp8_copies_equal_the_separate_quantise_pass():
     d = (got.float() - want.float()).abs()
     assert float(d.max()) <= 0.13 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
     assert abs(float(a3) - float(gf.abs().max())) < 1e-3 * float(gf.abs().max())
+    # ... and with no main output at all: the same copy, u still written, g untouched
+    g2 = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16); u2 = torch.empty_like(g2)
+    g8b = torch.zeros(M, N, dtype=torch.uint8, device="cuda"); a3b = torch.zeros(1, device="cuda")
+    epi = L.GemmEpilogue(bias.data_ptr(), None, None, u2.data_ptr(), None, 1.0, 1, L.BF16, 0, 0, 0, None, None, None, None, 0, None,
+                         g8b.data_ptr(), s3.data_ptr(), a3b.data_ptr(), 0)
+    L.check(h.ilvlm_gemm(L.BF16, 0, 0, M, N, K, a.data_ptr(), K, w.data_ptr(), K, None, N, C.byref(epi), 1, st), "gemm out8 only")
+    assert torch.equal(g8b, g8) and torch.equal(u2, u) and float(a3b) == float(a3)
+    epi = L.GemmEpilogue(bias.data_ptr(), None, None, None, None, 1.0, 0, L.BF16, 0, 0, 0, None)
+    assert h.ilvlm_gemm(L.BF16, 0, 0, M, N, K, a.data_ptr(), K, w.data_ptr(), K, None, N, C.byref(epi), 1, st) == -1   # no copy either
+    # LayerNorm with only the fp8 copy kept
+    y8b = torch.zeros_like(y8); amaxb = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_layernorm_fwd_q8(x.data_ptr(), L.F32, gamma.data_ptr(), beta.data_ptr(), None, L.BF16, mean.data_ptr(),
+                                     rstd.data_ptr(), rows, cols, 1e-5, 0, 0, y8b.data_ptr(), scale.data_ptr(), amaxb.data_ptr(), st), "ln_fwd_q8")
+    assert torch.equal(y8b, y8) and float(amaxb) == float(amax)
+    dx8b = torch.zeros_like(dx8); a2b = torch.zeros(1, device="cuda"); dxb = torch.empty_like(dx)
+    dg2, db2 = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    L.check(h.ilvlm_layernorm_bwd_q8(dy.data_ptr(), L.BF16, x.data_ptr(), L.F32, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     None, dxb.data_ptr(), None, L.BF16, 0, None, dg2.data_ptr(), db2.data_ptr(), rows, cols,
+                                     0, 0, None, 1, dx8b.data_ptr(), s2.data_ptr(), a2b.data_ptr(), st), "ln_bwd_q8")
+    assert torch.equal(dx8b, dx8) and torch.equal(dxb, dx) and float(a2b) == float(a2)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_attention_kernels_emit_the_fp8_copy_of_their_output(packed):
+    """fp8 mode: attention forward / backward write the e4m3 copy of `out` / the e5m2 copy of `dqkv` themselves: the same
+    bytes and amax as a quantise pass over the bf16 tensor; the backward may drop the bf16 tensor altogether"""
+    from ilvlm_amd import ops, lib as L
+    h = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    B, Lx, H = 5, 50, 4
+    E = 64 * H
+    if packed:
+        lens = [50, 7, 33, 1, 16]
+        seq = ops.PackedSeq(lens, Lx, "cuda")
+        rows, causal = sum(lens), 1
+        offs, cap = seq.offs.data_ptr(), seq.cap
+    else:
+        seq, rows, causal, offs, cap = None, B * Lx, 0, None, Lx
+    qkv = rnd(rows, 3 * E, seed=1).to(torch.bfloat16).cuda()
+    out = torch.empty(rows, E, device="cuda", dtype=torch.bfloat16); lse = torch.zeros(B, H, Lx, device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, Lx, H, causal, seq)
+    out2 = torch.empty_like(out); lse2 = torch.zeros_like(lse)
+    o8 = torch.zeros(rows, E, dtype=torch.uint8, device="cuda")
+    sc = torch.tensor([300.0], device="cuda"); am = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_attention_fwd_q8(qkv.data_ptr(), out2.data_ptr(), lse2.data_ptr(), L.BF16, B, Lx, cap, H, causal, offs,
+                                     o8.data_ptr(), sc.data_ptr(), am.data_ptr(), st), "attention_fwd_q8")
+    assert torch.equal(out2, out) and torch.equal(lse2, lse)
+    ref8 = torch.zeros_like(o8); ram = torch.zeros(1, device="cuda")
+    ops.fp8_quantize(out, ref8, sc, ram)
+    assert torch.equal(o8, ref8) and float(am) == float(ram)
+    # backward
+    dout = (rnd(rows, E, seed=2) * 1e-3).to(torch.bfloat16).cuda()
+    dqkv = torch.empty(rows, 3 * E, device="cuda", dtype=torch.bfloat16)
+    ops.attention_bwd(dout, qkv, out, lse, dqkv, B, Lx, H, causal, seq)
+    d8 = torch.zeros(rows, 3 * E, dtype=torch.uint8, device="cuda"); dq2 = torch.empty_like(dqkv)
+    s2 = torch.tensor([1.0e5], device="cuda"); a2 = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_attention_bwd_q8(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dq2.data_ptr(), L.BF16, B, Lx,
+                                     cap, H, causal, offs, d8.data_ptr(), s2.data_ptr(), a2.data_ptr(), st), "attention_bwd_q8")
+    assert torch.equal(dq2, dqkv)
+    ref8 = torch.zeros_like(d8); ram = torch.zeros(1, device="cuda")
+    ops.fp8_quantize(dqkv, ref8, s2, ram, e5m2=True)
+    assert torch.equal(d8, ref8) and float(a2) == float(ram)
+    d8b = torch.zeros_like(d8); a2b = torch.zeros(1, device="cuda")
+    L.check(h.ilvlm_attention_bwd_q8(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), None, L.BF16, B, Lx,
+                                     cap, H, causal, offs, d8b.data_ptr(), s2.data_ptr(), a2b.data_ptr(), st), "attention_bwd_q8 (copy only)")
+    assert torch.equal(d8b, d8) and float(a2b) == float(a2)
