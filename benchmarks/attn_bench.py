@@ -2,19 +2,26 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ilvlm_amd import ops
+from ilvlm_amd import ops, lib as L
+if os.environ.get("ILVLM_LIB_SUFFIX"):      # A/B builds of the library (csrc/Makefile variants)
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip%s.so" % os.environ["ILVLM_LIB_SUFFIX"])
 
-for (tag, B, L, H, causal) in [("vision", 256, 50, 12, 0), ("text", 256, 77, 8, 1), ("vit-l/14", 64, 257, 16, 0)]:
+g = torch.Generator().manual_seed(0)
+LENS = [int(v) for v in torch.randint(8, 78, (256,), generator=g)]        # bench.py's caption lengths
+for (tag, B, L, H, causal, packed) in [("vision", 256, 50, 12, 0, False), ("text", 256, 77, 8, 1, False),
+                                       ("text.packed", 256, 77, 8, 1, True), ("vit-l/14", 64, 257, 16, 0, False)]:
     E = 64 * H
-    qkv = torch.randn(B * L, 3 * E, device="cuda").to(torch.bfloat16)
-    dout = torch.randn(B * L, E, device="cuda").to(torch.bfloat16)
-    out = torch.empty(B * L, E, device="cuda", dtype=torch.bfloat16)
+    seq = ops.PackedSeq(LENS, L, "cuda") if packed else None
+    rows = seq.rows if packed else B * L
+    qkv = torch.randn(rows, 3 * E, device="cuda").to(torch.bfloat16)
+    dout = torch.randn(rows, E, device="cuda").to(torch.bfloat16)
+    out = torch.empty(rows, E, device="cuda", dtype=torch.bfloat16)
     dqkv = torch.empty_like(qkv)
-    lse = torch.empty(B, H, L, device="cuda")
+    lse = torch.zeros(B, H, L, device="cuda")
     flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     res = {}
-    for name, fn in [("fwd", lambda: ops.attention_fwd(qkv, out, lse, B, L, H, causal)),
-                     ("bwd", lambda: ops.attention_bwd(dout, qkv, out, lse, dqkv, B, L, H, causal))]:
+    for name, fn in [("fwd", lambda: ops.attention_fwd(qkv, out, lse, B, L, H, causal, seq)),
+                     ("bwd", lambda: ops.attention_bwd(dout, qkv, out, lse, dqkv, B, L, H, causal, seq))]:
         fn(); torch.cuda.synchronize()
         ts = []
         for it in range(10):

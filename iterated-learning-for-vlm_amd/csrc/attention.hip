@@ -95,6 +95,44 @@ __device__ __forceinline__ void stage_rows(bf16* dst, const bf16* src, long row_
         *(bf16x8*)(dst + r * LDH + ch * 8) = v;
     }
 }
+// The same staging split in two: every global load of a workgroup is issued before the first one is consumed.  Written as
+// one loop (load, convert, store) the compiler waits for each load right after issuing it, and a workgroup paid 6-8
+// memory round trips back to back before its first MFMA (17 us lifetime for ~2 us of arithmetic at L = 50).
+template <int ROWS, int NTH>
+struct RowRegs {
+    static constexpr int ITER = (ROWS * 8 + NTH - 1) / NTH;
+    bf16x8 v[ITER];
+    // range-checked buffer loads: rows >= L lie beyond the descriptor's extent and read as zeros -- no branch around the
+    // load for the compiler to sink the consumer into
+    __device__ __forceinline__ void load(const bf16* src, long row_stride, int L, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int rsb = (int)row_stride * 2;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, L > 0 ? (L - 1) * rsb + 128 : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
+            union { u32x4 u; bf16x8 h; } x;
+            x.u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, c < ROWS * 8 ? r * rsb + ch * 16 : 0x7ffffff0, 0, 0);
+            v[it] = x.h;
+        }
+#endif
+    }
+    __device__ __forceinline__ void store(bf16* dst, float scale, int tid) const {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
+            if (c < ROWS * 8) {
+                bf16x8 w = v[it];
+                if (scale != 1.0f)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (bf16)((float)w[j] * scale);
+                *(bf16x8*)(dst + r * LDH + ch * 8) = w;
+            }
+        }
+    }
+};
+
 // one operand fragment straight from global memory: 8 contiguous head-dim values of row `row` (zero beyond L)
 __device__ __forceinline__ bf16x8 frag_global(const bf16* src, long row_stride, int row, int L, int k32, int lane) {
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -129,8 +167,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_wave(const bf16* __restrict_
     bf16x8 qb[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qb[ks] = frag_global(base, rs, wave * 16 + c16, L, ks * 32, lane);
-    stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
-    stage_rows<ROWS, NTH>(Vs, base + 2 * E, rs, L, 1.0f, tid);
+    {
+        RowRegs<ROWS, NTH> rk, rv;
+        rk.load(base + E, rs, L, tid);
+        rv.load(base + 2 * E, rs, L, tid);
+        rk.store(Ks, 1.0f, tid);
+        rv.store(Vs, 1.0f, tid);
+    }
     __syncthreads();
     // NW == NT: one tile per wave; longer sequences (NW = 8 < NT): the wave walks tiles wave, wave + 8, ...
     for (int tile = wave; tile < NT; tile += NW) {
@@ -234,6 +277,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict_
     // requested before the staging loop so their latency hides behind it and the barrier
     // (up to 4 tiles = 32 registers; beyond that the occupancy lost costs more than the latency hidden, so longer sequences
     // fetch the fragments where they are used)
+    // (re-measured with the batched staging loads: no prefetch 76 us, prefetch at every length 62 us, 5 waves per SIMD
+    // forced 64 us, against 60 us for this form at L = 50)
     constexpr bool PREV = NT <= 4;
     bf16x8 vf[PREV ? NT : 1][2];
     if (PREV) {
@@ -243,32 +288,41 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_wave(const bf16* __restrict_
             vf[PREV ? kt : 0][1] = frag_global(vbase, rs, kt * 16 + (lane & 15), L, 32, lane);
         }
     }
-    stage_rows<ROWS, NTH>(Qs, base, rs, L, 0.125f, tid);
-    stage_rows<ROWS, NTH>(Ks, base + E, rs, L, 1.0f, tid);
     const bf16* dob = dout + row0 * E + h * HD;
     const bf16* ob = outp + row0 * E + h * HD;
-    constexpr int ITER = (ROWS * 8 + NTH - 1) / NTH;
+    {
+        RowRegs<ROWS, NTH> rq, rk, rd, ro;        // all loads in flight before the first is used
+        rq.load(base, rs, L, tid);
+        rk.load(base + E, rs, L, tid);
+        rd.load(dob, E, L, tid);
+        ro.load(ob, E, L, tid);
+        float lv[(ROWS + NTH - 1) / NTH];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {     // uniform trip count: every lane takes part in the shuffles
-        const int c = tid + it * NTH;
-        const int r = c >> 3, ch = c & 7;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        float part = 0.f;
-        if (c < ROWS * 8 && r < L) {
-            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
-            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
+        for (int i = 0; i < (ROWS + NTH - 1) / NTH; ++i) {
+            const int r = tid + i * NTH;
+            lv[i] = r < L ? lse[((long)b * H + h) * Lmax + r] : 0.f;
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        if (c < ROWS * 8) {
-            *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
-            if (ch == 0) delta[r] = part;
+        rq.store(Qs, 0.125f, tid);
+        rk.store(Ks, 1.0f, tid);
+        rd.store(dOs, 1.0f, tid);
+        constexpr int ITER = RowRegs<ROWS, NTH>::ITER;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {     // uniform trip count: every lane takes part in the shuffles
+            const int c = tid + it * NTH;
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)rd.v[it][j] * (float)ro.v[it][j];     // zero where the row is padding
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (c < ROWS * 8 && (c & 7) == 0) delta[c >> 3] = part;
+        }
+#pragma unroll
+        for (int i = 0; i < (ROWS + NTH - 1) / NTH; ++i) {
+            const int r = tid + i * NTH;
+            if (r < ROWS) lses[r] = lv[i];
         }
     }
-    for (int r = tid; r < ROWS; r += NTH) lses[r] = r < L ? lse[((long)b * H + h) * Lmax + r] : 0.f;
     __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
     for (int tile = wave; tile < NT; tile += NW) {
