@@ -21,15 +21,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     const float qs = (y8 && q_scale) ? q_scale[0] : 1.f;       // fp8 (e4m3) copy of the output for the fp8 GEMMs
     float qm = 0.f;
     const TX* xr = x + map_row(row, group, skip) * (long)cols;
-    f32x4 v[MAXV];
+    // Every load of the row is issued before the first is used, without a branch around it: behind `if (c < cols)` the
+    // compiler sinks the consumer into the branch and waits for each load in turn (3-4 memory round trips per row instead
+    // of one).  Chunks past the row are loaded from the row's last chunk and zeroed by a select.
+    f32x4 v[MAXV], gm[MAXV], bt[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + lane * 4, cc = c < cols ? c : cols - 4;
+        v[i] = load4<TX>(xr + cc);
+        gm[i] = *(const f32x4*)(gamma + cc);
+        bt[i] = *(const f32x4*)(beta + cc);
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        int c = i * 256 + lane * 4;
-        if (c < cols) {
-            v[i] = load4<TX>(xr + c);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
+        const int c = i * 256 + lane * 4;
+        if (c >= cols) v[i] = (f32x4){0, 0, 0, 0};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mu = wave_sum(s) / cols;
     float q = 0.f;
@@ -48,7 +56,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     for (int i = 0; i < MAXV; ++i) {
         int c = i * 256 + lane * 4;
         if (c < cols) {
-            f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c), o;
+            const f32x4 g = gm[i], b = bt[i];
+            f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
             if (y) store4<TY>(yr + c, o);
@@ -89,25 +98,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         const long srow = map_row(row, group, skip);
         const TX* xr = x + srow * (long)cols;
         const TDY* dyr = dy + row * (long)cols;
+        // all loads of the row first, branch-free (see ln_fwd_kernel): x, dy and the residual gradient; chunks past the row
+        // read the row's last chunk and are zeroed by a select
+        f32x4 xh[NV], gy[NV], dr[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 256 + lane * 4, cc = c < cols ? c : cols - 4;
+            xh[i] = load4<TX>(xr + cc);
+            gy[i] = load4<TDY>(dyr + cc);
+        }
+        if (dres) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4, cc = c < cols ? c : cols - 4;
+                dr[i] = *(const f32x4*)(dres + srow * (long)cols + cc);
+            }
+        }
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            int c = i * 256 + lane * 4;
-            if (c < cols) {
-                f32x4 xv = load4<TX>(xr + c), d = load4<TDY>(dyr + c);
+            const int c = i * 256 + lane * 4;
+            const f32x4 xv = xh[i];
+            f32x4 d = gy[i];
+            if (c >= cols) d = (f32x4){0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float h = (xv[j] - mu) * rs;
-                    xh[i][j] = h;
-                    ag[i][j] += d[j] * h;
-                    ab[i][j] += d[j];
-                    float t = d[j] * gm[i][j];
-                    gy[i][j] = t;
-                    s1 += t;
-                    s2 += t * h;
-                }
+            for (int j = 0; j < 4; ++j) {
+                float h = (xv[j] - mu) * rs;
+                xh[i][j] = h;
+                ag[i][j] += d[j] * h;
+                ab[i][j] += d[j];
+                float t = d[j] * gm[i][j];
+                gy[i][j] = t;
+                s1 += t;
+                s2 += t * h;
             }
         }
         s1 = wave_sum(s1) / cols;
@@ -119,11 +143,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
-                if (dres) o += *(const f32x4*)(dres + srow * (long)cols + c);
+                if (dres) o += dr[i];
                 if (dx_f32) *(f32x4*)(dx_f32 + srow * (long)cols + c) = o;
                 if (dx_lp || dx8 || q_amax) {      // the low-precision gradient; with dx8 alone only its fp8 copy is kept
                     if (act) {
-                        f32x4 u = load4<TLP>(act_aux + row * (long)cols + c);
+                        const f32x4 u = load4<TLP>(act_aux + row * (long)cols + c);     // FDT head only: not prefetched
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             o[j] *= act == ILVLM_ACT_QUICKGELU_BWD ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
