@@ -107,7 +107,8 @@ int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
 /* bf16 kernel selection (tuning / tests; process-wide atomic): 0 register-staged general kernel, 5 direct-to-LDS 128x128
  * (default), 6 direct-to-LDS 64x128 (K-contiguous A operand), 7 direct-to-LDS 256x128 with a 3-stage ring, 8 the 256x256
- * phased 8-wave kernel (one workgroup per CU), 9 direct-to-LDS 256x128 single stage.  Shapes the direct-to-LDS kernels
+ * phased 8-wave kernel (one workgroup per CU), 9 direct-to-LDS 256x128 single stage, 10 / 11 the weight-gradient form with a
+ * 2- / 3-deep operand ring (measured -3 % / -40 %, kept for A/B).  Shapes the direct-to-LDS kernels
  * cannot take (K % 64 != 0, ragged K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 

@@ -1353,6 +1353,11 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             // of the chip's 1024 workgroup slots empty (N = 512 / 768 outputs, the packed text rows;
             // benchmarks/gemm_bench.py) but 6.5 % SLOWER inside the two-stream step, where the other tower's kernels
             // fill those slots and the doubled weight re-reads cost more -- so it is never selected automatically.
+            // 10 / 11: the weight-gradient form with a 2- / 3-deep operand ring (64 / 96 KB of LDS, 2 / 1 workgroups per CU)
+            if (!swap && trans_a && trans_b && variant == 10)
+                return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
+            if (!swap && trans_a && trans_b && variant == 11)
+                return launch_dma<true, true, false, 128, 128, 2, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);
 #define ILVLM_DMA(TA, TB)                                                                                            \
     do {                                                                                                             \
         if (variant == 7)                                                                                            \
@@ -1397,7 +1402,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 9), "gemm_set_variant: 0, 5, 6, 7, 8 or 9");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 11), "gemm_set_variant: 0 or 5 .. 11");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }
