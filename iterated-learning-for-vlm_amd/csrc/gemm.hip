@@ -1358,6 +1358,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
             if (!swap && trans_a && trans_b && variant == 11)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);
+            if (!swap && trans_a && trans_b && variant == 12) {      // K-tiles of 128: 64 KB per workgroup and wait
+                int nt128 = ceil_div(K, 128);
+                return launch_dma<true, true, false, 128, 128, 2, 2, 1, 128>(a, lda, b, ldb, K, M, N, split_k > nt128 ? nt128 : split_k, ep, s);
+            }
 #define ILVLM_DMA(TA, TB)                                                                                            \
     do {                                                                                                             \
         if (variant == 7)                                                                                            \
@@ -1402,7 +1406,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 11), "gemm_set_variant: 0 or 5 .. 11");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 12), "gemm_set_variant: 0 or 5 .. 12");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }
