@@ -3,8 +3,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops, lib as L
-if os.environ.get("ILVLM_LIB_SUFFIX"):      # A/B builds of the library (csrc/Makefile variants)
-    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip%s.so" % os.environ["ILVLM_LIB_SUFFIX"])
 
 g = torch.Generator().manual_seed(0)
 LENS = [int(v) for v in torch.randint(8, 78, (256,), generator=g)]        # bench.py's caption lengths

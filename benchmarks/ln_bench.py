@@ -5,8 +5,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops, lib as L
-if os.environ.get("ILVLM_LIB_SUFFIX"):
-    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip%s.so" % os.environ["ILVLM_LIB_SUFFIX"])
 
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 

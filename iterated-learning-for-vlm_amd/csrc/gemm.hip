@@ -634,6 +634,12 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
 }
 #endif
 
+#ifndef ILVLM_FP8_SCALED_MFMA
+#define ILVLM_FP8_SCALED_MFMA 1      // K-contiguous fp8 operands (forward, input gradient): -9 % GEMM time, fp8 step +3.9 %
+#endif
+#ifndef ILVLM_FP8_SCALED_WGRAD
+#define ILVLM_FP8_SCALED_WGRAD 0     // K-strided fp8 operands (weight gradient): slower, see the main loop
+#endif
 // FP8 = 0: bf16 operands.  FP8 = 1 / 2: fp8 operands (OCP e4m3; 2: the A operand is e5m2, for gradients) addressed as if two
 // fp8 elements were one bf16 element -- the host passes K / 2, lda / 2, ldb / 2 -- so tiles, DMA and the LDS images are
 // byte for byte those of the bf16 kernel with a K-tile of 128 instead of 64; only the MFMA differs: every 16-byte
@@ -748,7 +754,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 #if ILVLM_GEMM_ABLATE == 1
         if (K < 0)
 #endif
-        if constexpr (TR8) {
+        if constexpr (TR8 && ILVLM_FP8_SCALED_WGRAD) {
+            // scaled MFMA over the whole 128-row K-tile (see the K-contiguous form below): lane (g, byte 8 s + j) holds
+            // k = 32 s + 8 g + j of its operand row, for both operands.  Measured SLOWER than the non-scaled form here
+            // (weight gradients 470 vs 437 us per block pair: four transposing reads per fragment before the first MFMA),
+            // so it is compiled out by default.
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            union F8 { long l[4]; v8i v; };
+            F8 fb8[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fb8[j].l[ks] = tr8_frag(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
+            F8 ones8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ones8.l[ks] = 0x3838383838383838L;       // e4m3 1.0
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                F8 fa8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa8.l[ks] = tr8_frag(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)      // first operand e4m3 (x), second e5m2 (dy)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j].v, fa8.v, acc[i][j], 0, 1, 0, 0x7f7f7f7f, 0,
+                                                                                 0x7f7f7f7f);
+                if (rowsum)
+                    accb[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8.v, fa8.v, accb[i], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        } else if constexpr (TR8) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 long fa8[TI], fb8[TJ];
@@ -766,6 +799,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
                     for (int i = 0; i < TI; ++i)
                         accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(0x3838383838383838L, fa8[i], accb[i], 0, 0, 0);
                 }
+            }
+        } else if constexpr ((FP8 == 1 || FP8 == 2) && ILVLM_FP8_SCALED_MFMA) {
+            // The block-scaled MFMA with all scales 2^0 as a plain fp8 MFMA: v_mfma_scale_f32_16x16x128_f8f6f4 takes the whole
+            // 128-byte K-tile of a fragment row per instruction (32 bytes per lane) and issues at twice the rate of the four
+            // non-scaled 16x16x32 fp8 instructions it replaces.  Both operands split their k bytes over (lane >> 4, byte)
+            // the same way -- the two 16-byte reads the non-scaled form does, concatenated -- so the products pair up.
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            static_assert(BKT == 64, "one instruction per 128-byte row");
+            union F8 { struct { bf16x8 lo, hi; } h; v8i v; };
+            F8 fb8[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                fb8[j].h.lo = p8_frag<TB, DBN, BKT>(bs, wn * (TJ * 16) + j * 16, 0, lane);
+                fb8[j].h.hi = p8_frag<TB, DBN, BKT>(bs, wn * (TJ * 16) + j * 16, 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                F8 fa8;
+                fa8.h.lo = p8_frag<TA, DBM, BKT>(as, wm * (TI * 16) + i * 16, 0, lane);
+                fa8.h.hi = p8_frag<TA, DBM, BKT>(as, wm * (TI * 16) + i * 16, 32, lane);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)      // cbsz / blgp: 0 = e4m3, 1 = e5m2; scale bytes 0x7f = 2^0
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j].v, fa8.v, acc[i][j], 0, FP8 == 2 ? 1 : 0, 0,
+                                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
             }
         } else
 #pragma unroll

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libilvlm_hip.so")
+# ILVLM_LIB_SUFFIX: A/B builds of the library next to the shipped one (benchmarks; csrc/Makefile's stamps / ablate targets)
+LIB_PATH = os.path.join(_HERE, "libilvlm_hip%s.so" % os.environ.get("ILVLM_LIB_SUFFIX", ""))
 
 F32, BF16, FP8, FP8_BF8A = 0, 1, 2, 3
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_QUICKGELU_BWD, ACT_GELU_ERF_BWD = 0, 1, 2, 3, 4
