@@ -13,18 +13,26 @@ namespace {
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline int esz(int dtype) { return dtype == ILVLM_BF16 ? 2 : 4; }
 
+// fp8 == 3 with all four weight matrices trainable: forward, input-gradient and weight-gradient GEMMs all read fp8 copies,
+// and the bf16 tensors nobody else reads are not written (a frozen weight keeps the fp8 == 2 behaviour for the whole block:
+// its bias gradient is a column sum over the bf16 gradient)
+inline bool fp8_all(const ilvlm_block* b) {
+    return b->fp8 == 3 && b->g_in_w && b->g_out_w && b->g_fc_w && b->g_proj_w;
+}
+
 struct Saved {   // byte offsets into the saved-activation workspace of one block
     size_t x_mid, h1, qkv, att, h2, u, g, mean1, rstd1, mean2, rstd2, lse, h1_8, att8, h2_8, g8, total;
     Saved(const ilvlm_block* b, long rows, int B, int L) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
         x_mid = o; o += al(r * E * 4);
-        h1 = o; o += al(r * E * es);
+        const bool lp_copies = !fp8_all(b);      // fully-fp8 blocks keep h1, h2 and g only as their e4m3 copies
+        h1 = o; if (lp_copies) o += al(r * E * es);
         qkv = o; o += al(r * 3 * E * es);
         att = o; o += al(r * E * es);
-        h2 = o; o += al(r * E * es);
+        h2 = o; if (lp_copies) o += al(r * E * es);
         u = o; o += al(r * 4 * E * es);
-        g = o; o += al(r * 4 * E * es);
+        g = o; if (lp_copies) o += al(r * 4 * E * es);
         mean1 = o; o += al(r * 4);
         rstd1 = o; o += al(r * 4);
         mean2 = o; o += al(r * 4);
@@ -48,12 +56,13 @@ struct Scratch {   // backward temporaries
     Scratch(const ilvlm_block* b, long rows) {
         const size_t E = b->E, es = esz(b->dtype), r = rows;
         size_t o = 0;
-        du = o; o += al(r * 4 * E * es);
+        const bool lp_copies = !fp8_all(b);      // fully-fp8 blocks: du, the bf16 copy of d(x_mid) and dqkv exist in e5m2 only
+        du = o; if (lp_copies) o += al(r * 4 * E * es);
         dh2 = o; o += al(r * E * es);
         dmid = o; o += al(r * E * 4);
-        dmid_lp = o; o += al(r * E * es);
+        dmid_lp = o; if (lp_copies) o += al(r * E * es);
         da = o; o += al(r * E * es);
-        dqkv = o; o += al(r * 3 * E * es);
+        dqkv = o; o += al(r * 3 * E * es);      // (kept: sequences above 128 tokens take the bf16 attention backward)
         dh1 = o; o += al(r * E * es);
         // e5m2 copies of the four gradients: separate regions, the weight-gradient stream reads each one while the main
         // stream is already producing the next (9 E bytes per row)
@@ -96,13 +105,6 @@ int wgrad_split(long out_rows, long out_cols, long k, int tile, int target) {
         int rc__ = (call);   \
         if (rc__) return rc__; \
     } while (0)
-
-// fp8 == 3 with all four weight matrices trainable: forward, input-gradient and weight-gradient GEMMs all read fp8 copies,
-// and the bf16 tensors nobody else reads are not written (a frozen weight keeps the fp8 == 2 behaviour for the whole block:
-// its bias gradient is a column sum over the bf16 gradient)
-inline bool fp8_all(const ilvlm_block* b) {
-    return b->fp8 == 3 && b->g_in_w && b->g_out_w && b->g_fc_w && b->g_proj_w;
-}
 
 enum { F8_H1 = 0, F8_ATT, F8_H2, F8_G, F8_IN_W, F8_OUT_W, F8_FC_W, F8_PROJ_W, F8_DOUT, F8_DU, F8_DMID, F8_DQKV };
 
