@@ -101,6 +101,16 @@ typedef struct ilvlm_gemm_epilogue {
     const float* out8_scale;
     float* out8_amax;
     int out8_fmt;
+    /* slab split-K for accumulate = 1, split_k > 1 (optional; all four NULL / 0 = fp32 atomics): every K-slice stores its
+     * 128x128 tile into the workspace, the workgroup drawing the tile's last ticket adds the slabs in slice order and is the
+     * only writer of C -- no atomics on C, and a sum that does not depend on arrival order.  splitk_ws: device buffer of
+     * splitk_ws_bytes >= tiles * split_k * 64 KiB; splitk_cnt: int32[splitk_cnt_len >= tiles], ZERO before first use (the
+     * kernel leaves it zero); one launch at a time per workspace (i.e. one workspace per stream).  Taken by the 128x128
+     * direct-to-LDS weight-gradient kernels (bf16 and fp8) for split_k <= 8; otherwise silently the atomic form. */
+    void* splitk_ws;
+    long splitk_ws_bytes;
+    int32_t* splitk_cnt;
+    int splitk_cnt_len;
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
@@ -308,6 +318,12 @@ typedef struct ilvlm_block {
     const float* f8_inv;
     float* f8_amax;
     int fp8;
+    /* slab split-K workspace for the block's weight-gradient GEMMs (see ilvlm_gemm_epilogue.splitk_*); NULL = atomics.  One
+     * workspace per weight-gradient stream. */
+    void* splitk_ws;
+    long splitk_ws_bytes;
+    int32_t* splitk_cnt;
+    int splitk_cnt_len;
 } ilvlm_block;
 long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L);
 long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);

@@ -133,7 +133,7 @@ int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, 
 // dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s.
 // dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given; x8 / inv_x: the
 // weight gradient on fp8 operands too (e5m2 dy^T, the e4m3 activation copy the forward pass kept), bias gradient as its row sums.
-int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
+int linear_bwd(const ilvlm_block* b, int dtype, const void* dy, const void* x, const void* W, float* gW, float* gb, void* dx, long M, int N, int K,
                int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
                const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr, void* dx8 = nullptr,
                const float* dx8_scale = nullptr, float* dx8_amax = nullptr, const void* x8 = nullptr,
@@ -158,6 +158,10 @@ int linear_bwd(int dtype, const void* dy, const void* x, const void* W, float* g
             ep.out_dtype = ILVLM_F32;
             ep.accumulate = 1;
             ep.a_rowsum = fuse_b ? gb : nullptr;
+            ep.splitk_ws = b->splitk_ws;
+            ep.splitk_ws_bytes = b->splitk_ws_bytes;
+            ep.splitk_cnt = b->splitk_cnt;
+            ep.splitk_cnt_len = b->splitk_cnt_len;
             const int split = wgrad_split(N, K, M, dtype == ILVLM_BF16 ? 128 : 64, wgrad_target);
             if (dy8 && x8) {
                 ep.alpha_ptr = inv_g;
@@ -315,10 +319,10 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // the e5m2 copy: the bf16 tensors are not written
     if (f8wg) du = nullptr;
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
-    TRY(linear_bwd(T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
+    TRY(linear_bwd(b, T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
                    g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,
                    f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G));
-    TRY(linear_bwd(T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
+    TRY(linear_bwd(b, T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
     if (f8wg) dmid_lp = nullptr;
@@ -327,7 +331,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
                                f8obs ? am + F8_DMID : nullptr, s));
     // attention
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
-    TRY(linear_bwd(T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
+    TRY(linear_bwd(b, T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT));
     if (f8on && Lq <= 128) {     // the wave-per-tile backward emits the e5m2 copy of dqkv itself
         if (f8wg) dqkv = nullptr;
@@ -339,7 +343,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
         else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
         TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, dqkv8, s, &g8));
     }
-    TRY(linear_bwd(T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
+    TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
                    inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1));
     return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32,
                                   lp ? din_lp : nullptr, T, 0,

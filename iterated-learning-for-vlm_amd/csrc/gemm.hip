@@ -602,7 +602,8 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
 // accumulate (split-K) epilogue: fragments (C^T orientation: lane owns row (l & 15), 4 consecutive columns) are
 // transposed through a wave-private 8 KiB LDS image so that every atomic wave-instruction covers 256 contiguous bytes
 // of one output row (the shape global float atomics run at full rate with)
-template <int TI, int TJ, int P = 0>
+// PLAIN: the caller is the only writer of the tile in this launch (slab reducer below): load-add-store instead of atomics
+template <int TI, int TJ, int P = 0, bool PLAIN = false>
 __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
                                                   float alpha, unsigned char* wlds) {
     static_assert(TJ == 4 && TI % 2 == 0, "64-column wave tile");
@@ -623,13 +624,16 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
             for (int r = 0; r < 32; ++r) {
                 const int m = m_base + P * 32 + r;
                 const float v = *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
-                if (m < ep.M && n < ep.N)
-                    atomicAdd(ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n, v * alpha);
+                if (m < ep.M && n < ep.N) {
+                    float* dst = ep.Cf + map_row(m, ep.e.out_group, ep.e.out_skip) * (long)ep.ldc + n;
+                    if constexpr (PLAIN) *dst += v * alpha;
+                    else atomicAdd(dst, v * alpha);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        epilogue_acc_tile<TI, TJ, P + 1>(ep, acc, m_base, n_base, lane, alpha, wlds);
+        epilogue_acc_tile<TI, TJ, P + 1, PLAIN>(ep, acc, m_base, n_base, lane, alpha, wlds);
     }
 }
 #endif
@@ -892,8 +896,63 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     if (SWAP) {
         epilogue_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
     } else {
-        // split-K accumulate: atomics in whole 256-byte row segments (see epilogue_acc_tile)
-        epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+        // split-K accumulate.  Default: fp32 atomics in whole 256-byte row segments (epilogue_acc_tile).  With a caller-provided
+        // workspace (ep.e.splitk_ws): every K-slice stores its tile as a slab with plain 16-byte stores, takes a ticket, and
+        // the workgroup that draws the last ticket of the tile adds the slabs up in slice order and is the only one to
+        // touch C -- the in-launch combine of cdna_hip_programming.md ("one agent-scope release + one agent-scope acquire
+        // per tile episode"): 28 MB of atomics at 1.3 TB/s become plain stores and loads, and the sum no longer depends on
+        // arrival order (bit-reproducible weight gradients).
+        if (ep.e.splitk_ws && split_k > 1) {
+            // Hand-off form (cdna_hip_programming.md, guideline 16, R1): the slabs are stored WRITE-THROUGH (sc1) and read with
+            // sc1 loads, so neither a release nor an acquire fence is needed -- the fenced form wrote back / invalidated whole
+            // L2s 432 times per launch and cost the step 8.6 %.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int tile_id = tm * tiles_n + tn;
+            const long nslab = (long)tiles_m * tiles_n * split_k;
+            __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(ep.e.splitk_ws, 0, (int)(nslab * (DBM * DBN * 4)), 0x00020000);
+            const int slab0 = tile_id * split_k * (DBM * DBN * 4);          // byte offsets (workspace < 2 GiB, host check)
+            const int mine = slab0 + z * (DBM * DBN * 4);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    union { f32x4 f; u32x4 u; } x;
+                    x.f = acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(x.u, ws, mine + ((i * TJ + j) * NT + tid) * 16, 0, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores
+            __syncthreads();
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(ep.e.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == split_k - 1;
+                if (last) __hip_atomic_store(ep.e.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+                *(volatile int*)smem_raw = last;        // broadcast through the one LDS array (the operand tiles are dead)
+            }
+            __syncthreads();
+            const int last = *(volatile int*)smem_raw;
+            __syncthreads();                            // wave 0's transpose slice starts at the flag word
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // compiler ordering only: loads stay below the ticket
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+                for (int zz = 0; zz < split_k; ++zz) {  // fixed order, own slab included; EVERY load of a slab is sc1
+                    const int sl = slab0 + zz * (DBM * DBN * 4);
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) {
+                            union { f32x4 f; u32x4 u; } x;
+                            x.u = __builtin_amdgcn_raw_buffer_load_b128(ws, sl + ((i * TJ + j) * NT + tid) * 16, 0, 16);
+                            acc[i][j] += x.f;
+                        }
+                }
+                epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+            }       // (the bias gradient of every slice still goes out below, as atomics on M floats)
+        } else {
+            epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+        }
         if (rowsum && lane < 16) {
             // fp8 operands: the row sums are sums of quantised values, de-quantised by the A operand's scale alone
             const float ra = (FP8 != 0 && ep.e.alpha_ptr) ? *ep.e.alpha_ptr : 1.f;
@@ -1358,6 +1417,24 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ep.ldc = ldc;
     ep.M = M;
     ep.N = N;
+    // slab split-K (epilogue fields splitk_*): offered by the caller, taken only by the 128x128 weight-gradient kernels and
+    // only when every K-slice is non-empty (each must draw a ticket), the split is small enough for one workgroup to add
+    // the slabs up, and the workspace holds tiles x split slabs
+    void* const slab_ws = epi->splitk_ws;
+    ep.e.splitk_ws = nullptr;
+    auto slab_setup = [&](int k_tile) {
+        if (!slab_ws || !epi->splitk_cnt || !epi->accumulate || split_k <= 1) return;
+        static const int max_split = getenv("ILVLM_SLAB_MAX_SPLIT") ? atoi(getenv("ILVLM_SLAB_MAX_SPLIT")) : 8;
+        const int nt_ = ceil_div(K, k_tile);
+        int sk = split_k < nt_ ? split_k : nt_;
+        while (sk > 1 && (long)(sk - 1) * ceil_div(nt_, sk) >= nt_) --sk;
+        const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+        if (sk > 1 && sk <= max_split && tiles <= epi->splitk_cnt_len && tiles * sk * (128L * 128 * 4) <= epi->splitk_ws_bytes &&
+            tiles * sk * (128L * 128 * 4) < (1L << 31)) {
+            split_k = sk;
+            ep.e.splitk_ws = slab_ws;
+        }
+    };
     size_t caln = epi->out_dtype == ILVLM_F32 ? 16 : 8;
     size_t auxaln = compute_dtype == ILVLM_F32 ? 16 : 8;
     if (fp8) {      // two fp8 elements are addressed as one bf16 element (gemm_bf16_dma_kernel, FP8)
@@ -1367,6 +1444,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         if (fp8_wgrad) {    // K-strided fp8 operands: byte addressing, K-tiles of 128 reduction rows
             int nt = ceil_div(K, 128);
             if (split_k > nt) split_k = nt;
+            slab_setup(128);
             return launch_dma<true, true, false, 128, 128, 2, 2, 1, 64, 3>((const bf16*)A, lda, (const bf16*)B, ldb, K, M, N, split_k, ep, s);
         }
         if (compute_dtype == ILVLM_FP8)
@@ -1410,6 +1488,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             // of the chip's 1024 workgroup slots empty (N = 512 / 768 outputs, the packed text rows;
             // benchmarks/gemm_bench.py) but 6.5 % SLOWER inside the two-stream step, where the other tower's kernels
             // fill those slots and the doubled weight re-reads cost more -- so it is never selected automatically.
+            if (!swap && (variant == 5 || variant >= 10)) slab_setup(variant == 12 ? 128 : 64);
             // 10 / 11: the weight-gradient form with a 2- / 3-deep operand ring (64 / 96 KB of LDS, 2 / 1 workgroups per CU)
             if (!swap && trans_a && trans_b && variant == 10)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);

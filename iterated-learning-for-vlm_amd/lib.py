@@ -19,7 +19,8 @@ class GemmEpilogue(C.Structure):
                 ("alpha", f32), ("act", i32), ("out_dtype", i32), ("accumulate", i32),
                 ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp),
                 ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32), ("alpha_ptr2", vp),
-                ("out8", vp), ("out8_scale", vp), ("out8_amax", vp), ("out8_fmt", i32)]
+                ("out8", vp), ("out8_scale", vp), ("out8_amax", vp), ("out8_fmt", i32),
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)]
 
 
 class Block(C.Structure):
@@ -29,7 +30,8 @@ class Block(C.Structure):
                                    "g_out_b", "g_fc_w", "g_fc_b", "g_proj_w", "g_proj_b")] +
                 [("E", i32), ("H", i32), ("causal", i32), ("dtype", i32)] +
                 [(n, vp) for n in ("in_w8", "out_w8", "fc_w8", "proj_w8", "in_w8t", "out_w8t", "fc_w8t", "proj_w8t", "f8_scale",
-                                   "f8_inv", "f8_amax")] + [("fp8", i32)])
+                                   "f8_inv", "f8_amax")] + [("fp8", i32)] +
+                [("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)])
 
 
 class AdamWHyper(C.Structure):

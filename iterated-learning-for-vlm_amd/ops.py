@@ -94,7 +94,7 @@ def set_gemm_profiler(p):
 
 def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, residual=None, aux=None, act=0,
          alpha=1.0, alpha_ptr=None, accumulate=False, out_group=0, out_skip=0, split_k=1, M=None, N=None, K=None,
-         a_rowsum=None):
+         a_rowsum=None, slab=None):
     """out[m,n] = epilogue(sum_k A(m,k) B(n,k)); see ilvlm_gemm.  a, b: 2-D bf16 or fp32 (same dtype);
     out: 2-D.  With out_group > 0, `out` is the token-stream tensor the rows are mapped into."""
     if a.dtype != b.dtype:
@@ -128,6 +128,9 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
         _chk(a_rowsum, "gemm.a_rowsum", torch.float32, (m,))
     epi = GemmEpilogue(_p(bias), _p(rowbias), _p(residual), _p(aux), _p(alpha_ptr), float(alpha), int(act), dt(out),
                        int(bool(accumulate)), int(out_group), int(out_skip), _p(a_rowsum))
+    if slab is not None:          # (workspace uint8, counters int32): slab split-K instead of atomics (ilvlm_gemm_epilogue)
+        epi.splitk_ws, epi.splitk_ws_bytes = slab[0].data_ptr(), slab[0].numel()
+        epi.splitk_cnt, epi.splitk_cnt_len = slab[1].data_ptr(), slab[1].numel()
     prof = _gemm_profiler if (_gemm_profiler is not None and a.dtype == torch.bfloat16) else None
     if _gemm_profiler is not None and prof is None:
         _gemm_profiler.f32_flops += 2.0 * m * n * k
@@ -179,7 +182,7 @@ def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual
     return out
 
 
-def gemm_fp8_wgrad(dy8, x8, out, scale_dy, scale_x, *, split_k=1, rowsum=None, K=None):
+def gemm_fp8_wgrad(dy8, x8, out, scale_dy, scale_x, *, split_k=1, rowsum=None, K=None, slab=None):
     """out[m,n] += inv_dy * inv_x * sum_t dy8[t,m] x8[t,n] (weight gradient in fp8 mode): dy8 [T,M] uint8 holding e5m2,
     x8 [T,N] uint8 holding e4m3, out fp32 [M,N]; rowsum[m] += inv_dy * sum_t dy8[t,m] (bias gradient)."""
     _chk(dy8, "gemm_fp8_wgrad.dy", torch.uint8); _chk(x8, "gemm_fp8_wgrad.x", torch.uint8)
@@ -192,6 +195,9 @@ def gemm_fp8_wgrad(dy8, x8, out, scale_dy, scale_x, *, split_k=1, rowsum=None, K
         _chk(rowsum, "gemm_fp8_wgrad.rowsum", torch.float32, (m,))
     epi = GemmEpilogue(None, None, None, None, scale_dy.data_ptr(), 1.0, 0, L.F32, 1, 0, 0, _p(rowsum),
                        None, None, None, 0, scale_x.data_ptr())
+    if slab is not None:
+        epi.splitk_ws, epi.splitk_ws_bytes = slab[0].data_ptr(), slab[0].numel()
+        epi.splitk_cnt, epi.splitk_cnt_len = slab[1].data_ptr(), slab[1].numel()
     prof = _gemm_profiler
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

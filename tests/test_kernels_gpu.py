@@ -654,6 +654,41 @@ def test_weight_gradient_gemm_at_full_size(M, N, K, split):
         assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,split", [(3072, 768, 12800, 3), (768, 3072, 12800, 3), (2304, 768, 12800, 4), (2048, 512, 11319, 6),
+                                         (304, 200, 1000, 5), (128, 128, 256, 4), (1536, 512, 11319, 8)])
+def test_slab_split_k_weight_gradient_is_right_and_bit_reproducible(M, N, K, split):
+    """split-K through slab workspaces (every K-slice stores its tile, the last arriver adds the slabs in slice order and
+    alone writes C): equal to the reference like the atomic form, bit-identical from launch to launch -- which the atomic
+    form is not --, accumulates into what C already holds, and leaves the ticket counters zero for the next launch (the
+    same workspace serves all 14 launches, of two shapes)."""
+    ops = _ops()
+    a, b = rnd(K, M, seed=1).to(torch.bfloat16).cuda(), rnd(K, N, seed=2).to(torch.bfloat16).cuda()
+    ref = a.float().t() @ b.float()
+    rs_ref = a.float().sum(0)
+    scale = float(ref.abs().max())
+    slab = (torch.empty(48 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(4096, dtype=torch.int32, device="cuda"))
+    slab[0].fill_(0xff)                                  # NaN patterns: an unwritten slab word would show
+    a2, b2 = rnd(512, 256, seed=3).to(torch.bfloat16).cuda(), rnd(512, 384, seed=4).to(torch.bfloat16).cuda()
+    base = rnd(M, N, seed=5).cuda() * scale
+    first = None
+    for it in range(12):
+        out = base.clone()
+        rs = torch.zeros(M, device="cuda")
+        ops.gemm(a, b, out, trans_a=True, trans_b=True, accumulate=True, split_k=split, a_rowsum=rs if M % 8 == 0 else None, slab=slab)
+        assert float((out - base - ref).abs().max()) < 1e-3 * scale, "launch %d" % it
+        if M % 8 == 0:
+            assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(out, first), "launch %d differs from the first" % it
+        if it % 5 == 4:                                  # another shape through the same workspace in between
+            o2 = torch.zeros(256, 384, device="cuda")
+            ops.gemm(a2, b2, o2, trans_a=True, trans_b=True, accumulate=True, split_k=2, slab=slab)
+            assert float((o2 - a2.float().t() @ b2.float()).abs().max()) < 1e-3 * float((a2.float().t() @ b2.float()).abs().max())
+    assert int(slab[1].abs().sum()) == 0                 # every ticket counter is back at zero
+
+
 @pytest.mark.parametrize("B,L,H,causal,packed", [(256, 77, 8, 1, True), (256, 50, 12, 0, False), (64, 257, 16, 0, False)])
 def test_attention_at_full_size_is_deterministic_and_right(B, L, H, causal, packed):
     """the step's attention launches at full size: repeated launches bit-identical (no atomics), a sample of sequences equal to
