@@ -144,12 +144,15 @@ class GradReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t.div_(W)
 
-    def reduce_range(self, begin, end, chunk_elems=32 * 1024 * 1024):
-        """Enqueue the mean of flat[begin:end]; the producer stream's work so far is waited for."""
+    def reduce_range(self, begin, end, chunk_elems=32 * 1024 * 1024, also_wait=None):
+        """Enqueue the mean of flat[begin:end]; the producer stream's work so far is waited for (and that of `also_wait`, the
+        weight-gradient companion of the producer stream: the communication stream waits for it, the producer does not)."""
         if not _active(self.W) or end <= begin:
             return
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            if also_wait is not None:
+                self.stream.wait_stream(also_wait)
             ctx = torch.cuda.stream(self.stream)
         else:
             ctx = contextlib.nullcontext()

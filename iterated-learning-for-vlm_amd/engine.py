@@ -587,7 +587,7 @@ class Engine:
                                            cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None, f8_in=carry,
                                            f8_next=("visual.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
             carry = self._f8_carry
-            if self.arena.reducing() or self.join_each_block:
+            if self.join_each_block:      # (a gradient reducer waits for the companion stream itself: comm.reduce_range)
                 self.join_wgrad()
             self.m._sync("visual.transformer.resblocks.%d." % i)       # this block's gradients are complete
         if st is not None:
@@ -671,7 +671,7 @@ class Engine:
                                            f8_in=carry,
                                            f8_next=("encode_text.transformer.resblocks.%d." % (i - 1)) if i > 0 else None)
             carry = self._f8_carry
-            if self.arena.reducing() or self.join_each_block:
+            if self.join_each_block:      # (a gradient reducer waits for the companion stream itself: comm.reduce_range)
                 self.join_wgrad()
             self.m._sync("encode_text.transformer.resblocks.%d." % i)
         if st is not None:

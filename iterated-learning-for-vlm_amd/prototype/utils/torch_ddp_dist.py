@@ -73,7 +73,11 @@ class NativeDDP(nn.Module):
 
     def _reduce(self, b, e):
         if e > b:
-            self.module._eng.arena.reducer.reduce_range(b, e)
+            eng = self.module._eng
+            # the range's weight gradients come from the companion of the announcing stream: the communication stream waits
+            # for both, so the tower's own stream never has to join its companion in the middle of backward
+            wg = eng._wg.get(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else None
+            eng.arena.reducer.reduce_range(b, e, also_wait=wg)
             self._done.append((b, e))
 
     def _on_sync(self, what):
