@@ -474,19 +474,21 @@ enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, 
 
 // one pass (32 rows: row tiles 2P, 2P+1) of epilogue_tile; the pass index is a template parameter so that the accumulator
 // array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
-template <int MODE, int TI, int TJ, int P>
+// RT = row tiles per pass: 2 (32 rows, 8 KiB of LDS per wave) or 1 (16 rows, 4 KiB: the persistent kernel, whose operand
+// LDS is being refilled while the epilogue runs)
+template <int MODE, int TI, int TJ, int P, int RT = 2>
 __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n, int lane, float alpha,
                                               unsigned char* wlds, f32x4 bias, float& amax8) {
-    if constexpr (P < TI / 2) {
+    if constexpr (P < TI / RT) {
         const ilvlm_gemm_epilogue& e = ep.e;
         const int g = lane >> 4, c = lane & 15;
         // fragments of row tiles 2P, 2P+1 -> [32 rows][64 fp32] image, 16-byte chunk index XOR (row & 15)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < RT; ++ii)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int row = ii * 16 + c;
-                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[2 * P + ii][j];
+                *(f32x4*)(wlds + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[RT * P + ii][j];
             }
         // lanes read what OTHER lanes wrote: per thread the stores above and the loads below touch different addresses, so
         // the compiler is free to reorder them unless told otherwise (a release fence alone lets the loads move up).  The
@@ -500,8 +502,8 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
             int cur = -1;
             unsigned long long best = 0;
 #pragma unroll 1
-            for (int r = 0; r < 32; ++r) {
-                const int m = m_base + P * 32 + r;
+            for (int r = 0; r < 16 * RT; ++r) {
+                const int m = m_base + P * (16 * RT) + r;
                 if (m >= ep.M) break;                                  // wave-uniform
                 const float v = alpha * *(const float*)(wlds + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
                 int sq, tok;
@@ -521,19 +523,19 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
         } else if constexpr (MODE == EPI_GENERIC) {
             // ragged tile, unaligned operands or a rare epilogue (row-indexed bias): one bounds-checked call per 4-row group
 #pragma unroll 1
-            for (int hk = 0; hk < 8; ++hk) {
+            for (int hk = 0; hk < 4 * RT; ++hk) {
                 const int row = 4 * hk + g;
                 const f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
-                epilogue4<bf16>(ep, m_base + P * 32 + row, n, v, alpha, (e.out8 || e.out8_amax) ? &amax8 : nullptr);
+                epilogue4<bf16>(ep, m_base + P * (16 * RT) + row, n, v, alpha, (e.out8 || e.out8_amax) ? &amax8 : nullptr);
             }
         } else {
 #pragma unroll 1
-            for (int h = 0; h < 2; ++h) {            // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
+            for (int h = 0; h < RT; ++h) {           // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
                 f32x4 pre[4];
                 long off[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {        // every load of the half-pass before its first store (vmcnt counts both)
-                    const int m = m_base + P * 32 + h * 16 + 4 * k + g;
+                    const int m = m_base + P * (16 * RT) + h * 16 + 4 * k + g;
                     off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
                     if constexpr (MODE == EPI_RES) pre[k] = *(const f32x4*)(e.residual + off[k]);
                     if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) pre[k] = load4<bf16>((const bf16*)e.aux + off[k]);
@@ -563,15 +565,15 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
-        epilogue_pass<MODE, TI, TJ, P + 1>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
+        epilogue_pass<MODE, TI, TJ, P + 1, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
     }
 }
 
-template <int TI, int TJ>
+template <int TI, int TJ, int RT = 2>
 __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
                                               float alpha, unsigned char* wlds) {
     const ilvlm_gemm_epilogue& e = ep.e;
-    static_assert(TJ == 4 && (TI % 2) == 0, "64-column wave tiles, row tiles in pairs");
+    static_assert(TJ == 4 && (TI % RT) == 0, "64-column wave tiles, RT row tiles per pass");
     const bool whole = ep.vec_ok && !e.accumulate && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
     int mode = EPI_GENERIC;
     if (e.pool_out) mode = EPI_POOLMAX;
@@ -583,14 +585,14 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
     const f32x4 bias = (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
     float amax8 = 0.f;
     switch (mode) {
-        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        default: epilogue_pass<EPI_GENERIC, TI, TJ, 0>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        default: epilogue_pass<EPI_GENERIC, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
     }
     if (e.out8_amax) {          // one conditional atomic per wave and tile
         amax8 = wave_max(amax8);
@@ -975,6 +977,84 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 }
 
 // =====================================================================================
+// Persistent form of the 128x128x64 kernel for the store-type GEMMs (forward, input gradient; variant 13, A/B).
+// What the round-2 measurements say bounds the default kernel on the step's K = 512...768 shapes is not the K-loop (it runs
+// at the L2->LDS ceiling) but that a workgroup slot moves operand bytes only about half of its lifetime: first-tile latency
+// before, epilogue after.  Here a workgroup walks tiles v = blockIdx.x, + gridDim.x, ...; when the K-loop of a tile ends it
+// issues the FIRST K-tile of its next tile and only then runs the epilogue, which transposes through 4 KiB per wave BEHIND
+// the operand buffers (16-row passes) -- the refill lands while the stores drain.  48 KiB of LDS: three workgroups per CU.
+// =====================================================================================
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_persist_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                                   int ldb, int K, int tiles_m, int tiles_n, EpiArgs ep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int DBM = 128, DBN = 128, BKT = 64, NT = 256, TI = 4, TJ = 4, A_BYTES = DBM * BKT * 2, OPER = 2 * A_BYTES;
+    typedef DmaOperand<TA, DBM, NT, BKT> OpA;
+    typedef DmaOperand<TB, DBN, NT, BKT> OpB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = tiles_m * tiles_n, nt = K / BKT;
+    int v = blockIdx.x;                       // gridDim.x is a multiple of 8: every tile of this workgroup maps to its own XCD
+    if (v >= ntiles) return;
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
+    OpA opa; OpB opb;
+    int wg = xcd_remap(v, ntiles);
+    int tn = wg % tiles_n, tm = wg / tiles_n;
+    opa.init(A, lda, tm * DBM, ep.M, K, wave, lane);
+    opb.init(B, ldb, tn * DBN, ep.N, K, wave, lane);
+    opa.issue(0, smem_raw, wave);
+    opb.issue(0, smem_raw + A_BYTES, wave);
+    f32x4 acc[TI][TJ];
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ILVLM_WG_BARRIER();
+            const unsigned char* as = smem_raw;
+            const unsigned char* bs = smem_raw + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BKT / 32; ++ks) {
+                bf16x8 fa[TI], fb[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, ks * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, ks * 32, lane);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            ILVLM_WG_BARRIER();               // every wave is done with the tile before it is overwritten
+            if (t + 1 < nt) {
+                opa.issue(t + 1, smem_raw, wave);
+                opb.issue(t + 1, smem_raw + A_BYTES, wave);
+            }
+        }
+        const int mw = tm * DBM + wm * 64, nw = tn * DBN + wn * 64;
+        const int vn = v + gridDim.x;
+        if (vn < ntiles) {                    // refill for the next tile first, then the epilogue of this one
+            wg = xcd_remap(vn, ntiles);
+            tn = wg % tiles_n; tm = wg / tiles_n;
+            opa.init(A, lda, tm * DBM, ep.M, K, wave, lane);
+            opb.init(B, ldb, tn * DBN, ep.N, K, wave, lane);
+            opa.issue(0, smem_raw, wave);
+            opb.issue(0, smem_raw + A_BYTES, wave);
+        }
+        epilogue_tile<TI, TJ, 1>(ep, acc, mw, nw, lane, alpha, smem_raw + OPER + wave * 4096);
+        if (vn >= ntiles) break;
+        v = vn;
+    }
+#endif
+}
+
+// =====================================================================================
 // bf16 "phased" kernel: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), one workgroup per CU, 128 KiB of LDS =
 // two K-tile buffers of four 16 KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255).
 //
@@ -1337,6 +1417,18 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
+template <bool TA, bool TB>
+int launch_persist(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_persist_kernel<TA, TB>;
+    constexpr int bytes = 32768 + 4 * 4096;
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
+    static const int wgs = getenv("ILVLM_PERSIST_WGS") ? atoi(getenv("ILVLM_PERSIST_WGS")) : 768;     // 3 per CU
+    int grid = tm * tn < wgs ? (tm * tn + 7) / 8 * 8 : wgs;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, s, A, lda, B, ldb, K, tm, tn, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_persist");
+    return ILVLM_OK;
+}
+
 template <bool TA, bool TB, bool ACC>
 int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
     auto kern = gemm_bf16_p8_kernel<TA, TB, ACC>;
@@ -1488,6 +1580,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             // of the chip's 1024 workgroup slots empty (N = 512 / 768 outputs, the packed text rows;
             // benchmarks/gemm_bench.py) but 6.5 % SLOWER inside the two-stream step, where the other tower's kernels
             // fill those slots and the doubled weight re-reads cost more -- so it is never selected automatically.
+            if (swap && variant == 13 && !trans_a && K % BK == 0) {     // persistent 128x128 (A/B)
+                if (trans_b) return launch_persist<false, true>(a, lda, b, ldb, K, M, N, ep, s);
+                return launch_persist<false, false>(a, lda, b, ldb, K, M, N, ep, s);
+            }
             if (!swap && (variant == 5 || variant >= 10)) slab_setup(variant == 12 ? 128 : 64);
             // 10 / 11: the weight-gradient form with a 2- / 3-deep operand ring (64 / 96 KB of LDS, 2 / 1 workgroups per CU)
             if (!swap && trans_a && trans_b && variant == 10)
@@ -1542,7 +1638,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 12), "gemm_set_variant: 0 or 5 .. 12");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 13), "gemm_set_variant: 0 or 5 .. 13");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }

@@ -52,7 +52,7 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1
 GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 13])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 392, 256), (136, 2304, 768), (8, 8, 128), (512, 256, 64),
                                    (776, 520, 192)])
@@ -611,7 +611,7 @@ def test_weight_gradient_gemm_with_ragged_reduction(K):
     assert rel(bias, a.float().sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 13])
 @pytest.mark.parametrize("M,N,K,tb", [(19712, 2048, 512, 0), (12800, 3072, 768, 0), (12800, 768, 3072, 1), (11319, 1536, 512, 0)])
 def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, tb):
     """Chip-filling launches of the step's shapes, repeated: every launch must reproduce the first bit for bit (no atomics in
