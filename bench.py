@@ -224,7 +224,8 @@ def main():
         sched.step(state["step"])
         (li, lt), _ = ddp(images, texts)
         loss, target = crit(li, lt)
-        loss = loss / world
+        if world > 1:                   # (the reference divides unconditionally: train_solver.py:420; a no-op kernel at one rank)
+            loss = loss / world
         prec1, prec5 = accuracy(li, target, topk=(1, 5))
         opt.zero_grad()
         ops.clamp_(model.logit_scale.data, 3, 6)

@@ -25,9 +25,16 @@ class _InfoNCE(torch.autograd.Function):
 
 
 class ClipInfoCELoss(_Loss):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._labels = {}       # (batch, offset, device) -> label vector: built once, not with two ATen kernels per step
+
     def forward(self, logits_per_image, logits_per_text):
         bs, l_bs = logits_per_image.shape
         offset = 0 if l_bs == bs else link.get_rank() * bs
-        labels = offset + torch.arange(bs, dtype=torch.long, device=logits_per_image.device)
+        key = (bs, offset, logits_per_image.device)
+        labels = self._labels.get(key)
+        if labels is None:
+            labels = self._labels[key] = offset + torch.arange(bs, dtype=torch.long, device=logits_per_image.device)
         loss = _InfoNCE.apply(logits_per_image, logits_per_text, offset)
         return loss, labels

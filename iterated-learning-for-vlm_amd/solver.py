@@ -370,7 +370,8 @@ class ClsSolver:
         out = self.model(image, text)
         logits = out[0] if self.fdt else out
         loss, target = self.criterion(logits[0], logits[1])
-        loss = loss / self.world_size
+        if self.world_size > 1:         # reference: unconditional (train_solver.py:420); at one rank it is x / 1
+            loss = loss / self.world_size
         prec1, prec5 = accuracy(logits[0], target, topk=(1, self.topk))
         self.optimizer.zero_grad()
         self._clamp_logit_scale()
