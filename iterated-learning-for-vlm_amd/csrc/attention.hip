@@ -481,26 +481,43 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restric
     const int E = HD * H;
     const long rs = 3L * E;
     const bf16* base = qkv + (long)b * L * rs + h * HD;
-    load_rows<LP>(Qs, base, rs, L, 0.125f, tid);
     const bf16* dob = dout + (long)b * L * E + h * HD;
     const bf16* ob = outp + (long)b * L * E + h * HD;
-    for (int c = tid; c < LP * 8; c += 256) {
-        int r = c >> 3, ch = c & 7;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        float part = 0.f;
-        if (r < L) {
-            v = *(const bf16x8*)(dob + (long)r * E + ch * 8);
-            bf16x8 o = *(const bf16x8*)(ob + (long)r * E + ch * 8);
+    {
+        // One workgroup per CU (138 KB of LDS at L = 257): nothing hides a load but the workgroup itself.  All Q / dO / O rows
+        // are requested before the first is consumed (RowRegs: 6-9 x 16 bytes per thread and tensor; the loop form paid one
+        // memory round trip per iteration, 27 in a row), the first key block's K / V right behind them.
+        RowRegs<LP, 256> rq, rd, ro;
+        rq.load(base, rs, L, tid);
+        rd.load(dob, E, L, tid);
+        ro.load(ob, E, L, tid);
+        constexpr int NL = (LP + 255) / 256;
+        float lv[NL];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part += (float)v[j] * (float)o[j];
+        for (int i = 0; i < NL; ++i) {
+            const int r = tid + i * 256;
+            lv[i] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
         }
-        *(bf16x8*)(dOs + r * LDH + ch * 8) = v;
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        if (ch == 0) delta[r] = part;
+        rq.store(Qs, 0.125f, tid);
+        rd.store(dOs, 1.0f, tid);
+        constexpr int ITER = RowRegs<LP, 256>::ITER;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tid + it * 256;
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)rd.v[it][j] * (float)ro.v[it][j];
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (c < LP * 8 && (c & 7) == 0) delta[c >> 3] = part;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = tid + i * 256;
+            if (r < LP) lses[r] = lv[i];
+        }
     }
-    for (int r = tid; r < LP; r += 256) lses[r] = r < L ? lse[((long)b * H + h) * L + r] : 0.f;
 
     const int g = lane >> 4, c16 = lane & 15;
     f32x4 dq[NA][4];
@@ -509,16 +526,25 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restric
 #pragma unroll
         for (int d = 0; d < 4; ++d) dq[a][d] = (f32x4){0, 0, 0, 0};
 
+    // K / V rows of a key block: 32 rows x 8 chunks = 256 chunks each, one per thread; block kb + 1 is requested while block
+    // kb is computed on and parked in registers until the block's last barrier
+    const int kr = tid >> 3, kch = tid & 7;
+    bf16x8 kv_n = {0, 0, 0, 0, 0, 0, 0, 0}, vv_n = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kr < L) {
+        kv_n = *(const bf16x8*)(base + E + (long)kr * rs + kch * 8);
+        vv_n = *(const bf16x8*)(base + 2 * E + (long)kr * rs + kch * 8);
+    }
     for (int kb = 0; kb < LP / KB; ++kb) {
-        {   // this key block's K and V rows: 32 rows x 8 chunks = 256 chunks each, one per thread
-            const int r = tid >> 3, ch = tid & 7, key = kb * KB + r;
-            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (key < L) {
-                kv = *(const bf16x8*)(base + E + (long)key * rs + ch * 8);
-                vv = *(const bf16x8*)(base + 2 * E + (long)key * rs + ch * 8);
+        *(bf16x8*)(Ks + kr * LDH + kch * 8) = kv_n;
+        *(bf16x8*)(Vs + kr * LDH + kch * 8) = vv_n;
+        {
+            const int key = (kb + 1) * KB + kr;
+            kv_n = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            vv_n = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (kb + 1 < LP / KB && key < L) {
+                kv_n = *(const bf16x8*)(base + E + (long)key * rs + kch * 8);
+                vv_n = *(const bf16x8*)(base + 2 * E + (long)key * rs + kch * 8);
             }
-            *(bf16x8*)(Ks + r * LDH + ch * 8) = kv;
-            *(bf16x8*)(Vs + r * LDH + ch * 8) = vv;
         }
         __syncthreads();
         // phase 1: P and dS of this key block for the wave's query tiles
