@@ -199,6 +199,41 @@ def test_fp8_mode_tiny_model_tracks_bf16():
     assert min(cos) > 0.8 and sorted(cos)[len(cos) // 2] > 0.95, (min(cos), sorted(cos)[len(cos) // 2])
 
 
+def test_fp8_mode_vitl14_tracks_bf16():
+    """fp8 mode at the ViT-L/14 + FDT geometry (width 1024, 257 tokens: the forward attention emits the e4m3 copy itself,
+    the key-block backward falls back to the separate quantise pass of dqkv), batch 8: logits stay within fp8's accuracy
+    of the bf16 model, sampled weight gradients keep their direction"""
+    import bench as B
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    images, tokens, pad, lens = B.synthetic_batch(8, 0, "cuda")
+    outs = {}
+    for prec in ("fp8", "bf16"):
+        torch.manual_seed(0)
+        m = model_entry(dict(type="clip_fdt_vitL14", kwargs=B.fdt_kwargs(prec, "vitl14"))).cuda().train()
+        for it in range(2):
+            (li, lt), _ = m(images, (tokens, pad, lens))
+            loss, _ = ClipInfoCELoss()(li, lt)
+            m.zero_grad()
+            loss.backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()
+                 if p.grad is not None and ("resblocks.0." in n or "resblocks.11." in n or "resblocks.23." in n) and p.dim() == 2}
+        outs[prec] = (li.detach().float().cpu(), grads)
+        if prec == "fp8":
+            assert m.engine.fp8.active
+        del m
+    ref = outs["bf16"][0]
+    err = float((outs["fp8"][0] - ref).abs().max() / ref.abs().max())
+    assert err < 5e-2, err
+    cos = []
+    for n, g in outs["bf16"][1].items():
+        a, b = outs["fp8"][1][n].double().flatten(), g.double().flatten()
+        cos.append(float((a * b).sum() / (a.norm() * b.norm())))
+    # measured: min 0.926, median 0.946 over 20 matrices of blocks 0 / 11 / 23 (24 layers of e5m2 gradients at batch 8)
+    assert len(cos) >= 16 and min(cos) > 0.85 and sorted(cos)[len(cos) // 2] > 0.92, (min(cos), sorted(cos)[len(cos) // 2])
+
+
 def test_fp8_loss_curve_tracks_bf16_at_real_size():
     """BASELINE configs[4] validation at reduced length (benchmarks/fp8_loss_curve.py runs the >= 200-step curve): the
     shipped geometry, per-GPU batch 64, AdamW + the cosine schedule, 24 steps on one resident synthetic batch (what
