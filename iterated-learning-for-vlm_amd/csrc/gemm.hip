@@ -984,7 +984,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 // issues the FIRST K-tile of its next tile and only then runs the epilogue, which transposes through 4 KiB per wave BEHIND
 // the operand buffers (16-row passes) -- the refill lands while the stores drain.  48 KiB of LDS: three workgroups per CU.
 // =====================================================================================
-template <bool TA, bool TB>
+template <bool TA, bool TB, int FP8 = 0>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_persist_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
                                                                    int ldb, int K, int tiles_m, int tiles_n, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1019,6 +1019,26 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_persist_kernel(const bf16* _
             ILVLM_WG_BARRIER();
             const unsigned char* as = smem_raw;
             const unsigned char* bs = smem_raw + A_BYTES;
+            if constexpr (FP8 != 0) {         // fp8 operands, two per bf16 slot: the block-scaled MFMA with unit scales (see above)
+                typedef int v8i __attribute__((ext_vector_type(8)));
+                union F8 { struct { bf16x8 lo, hi; } h; v8i v; };
+                F8 fb8[TJ];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    fb8[j].h.lo = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, 0, lane);
+                    fb8[j].h.hi = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, 32, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    F8 fa8;
+                    fa8.h.lo = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, 0, lane);
+                    fa8.h.hi = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, 32, lane);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j].v, fa8.v, acc[i][j], 0, FP8 == 2 ? 1 : 0, 0,
+                                                                                     0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < BKT / 32; ++ks) {
                 bf16x8 fa[TI], fb[TJ];
@@ -1417,9 +1437,9 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int FP8 = 0>
 int launch_persist(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_persist_kernel<TA, TB>;
+    auto kern = gemm_bf16_persist_kernel<TA, TB, FP8>;
     constexpr int bytes = 32768 + 4 * 4096;
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
     static const int wgs = getenv("ILVLM_PERSIST_WGS") ? atoi(getenv("ILVLM_PERSIST_WGS")) : 768;     // 3 per CU
@@ -1538,6 +1558,11 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             if (split_k > nt) split_k = nt;
             slab_setup(128);
             return launch_dma<true, true, false, 128, 128, 2, 2, 1, 64, 3>((const bf16*)A, lda, (const bf16*)B, ldb, K, M, N, split_k, ep, s);
+        }
+        if (g_gemm_variant.load(std::memory_order_relaxed) == 13) {     // persistent form (A/B)
+            if (compute_dtype == ILVLM_FP8)
+                return launch_persist<false, false, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N, ep, s);
+            return launch_persist<false, false, 2>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N, ep, s);
         }
         if (compute_dtype == ILVLM_FP8)
             return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N,
