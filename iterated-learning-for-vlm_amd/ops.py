@@ -4,6 +4,7 @@ wrappers check shapes/dtypes on the host (a kernel that indexes out of bounds ca
 down) and raise RuntimeError on any failure; there is no fallback path."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -231,8 +232,7 @@ def rowsum_fusable(m, k):
     return m % 8 == 0 and m >= 8
 
 
-import os as _os
-_WGRAD_TARGET = int(_os.environ.get("ILVLM_WGRAD_TARGET", "384"))
+_WGRAD_TARGET = int(os.environ.get("ILVLM_WGRAD_TARGET", "384"))
 
 
 def wgrad_split(out_rows, out_cols, k, tile=128):
@@ -243,9 +243,6 @@ def wgrad_split(out_rows, out_cols, k, tile=128):
 
 
 # ---------------------------------------------------------------------------------------------
-import os as _os_ln
-
-
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, group=0, skip=0):
     L.check(L.load().ilvlm_layernorm_fwd(x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dt(y),
                                          mean.data_ptr(), rstd.data_ptr(), rows, cols, eps, group, skip, _stream()),
@@ -255,7 +252,7 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, group=0, 
 # workgroups of a LayerNorm backward launch = partial dgamma / dbeta rows for its second stage.  512 (x 4 waves, grid-stride
 # over the rows): the backward kernel holds 144 VGPRs at width 768, so only 768 workgroups are resident at once and a grid
 # of 1024 ran a second, quarter-full round; measured 45.9 -> 41.1 us for backward + second stage at 12800 x 768.
-LN_WS_BLOCKS = int(_os_ln.environ.get("ILVLM_LN_WS_BLOCKS", "512"))
+LN_WS_BLOCKS = int(os.environ.get("ILVLM_LN_WS_BLOCKS", "512"))
 _ln_ws = {}
 
 
