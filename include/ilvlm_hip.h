@@ -120,7 +120,8 @@ int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K,
  * phased 8-wave kernel (one workgroup per CU), 9 direct-to-LDS 256x128 single stage, 10 / 11 the weight-gradient form with a
  * 2- / 3-deep operand ring (measured -3 % / -40 %), 12 the weight-gradient form with 128-deep K-tiles (+6..10 % alone at
  * the same split, -1.7 % inside the step), 13 a persistent 128x128 kernel for the store-type GEMMs that refills its operand
- * buffers for the next tile ahead of the epilogue stores (-2.5 % inside the step); all kept for A/B.  Shapes the direct-to-LDS kernels
+ * buffers for the next tile ahead of the epilogue stores (-2.5 % inside the step), 14 the stream-K form of the 256x256 phased
+ * kernel (needs the splitk_* workspace of the epilogue: 64 MiB + zeroed counters; -10 % inside the step); all kept for A/B.  Shapes the direct-to-LDS kernels
  * cannot take (K % 64 != 0, ragged K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 

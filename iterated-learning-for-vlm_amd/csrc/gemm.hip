@@ -1319,6 +1319,135 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const bf16* __rest
 }
 
 // =====================================================================================
+// Stream-K form of the phased 256x256 kernel for the store-type GEMMs with few tiles and a deep K (N <= 768, K >= 1536:
+// 150 / 90 tiles for 256 CUs; variant 14 / ILVLM_GEMM_AUTO8).  One workgroup per CU; the tiles x K-tiles iterations are cut
+// into gridDim.x equal contiguous ranges.  A range starts inside a tile (its TAIL part: the partial sums go out at once as
+// a slab -- write-through stores, then a ticket on the tile) and may continue into the next tile from k = 0 (its HEAD part):
+// the workgroup holding k = 0 owns the tile, waits for the tile's tickets, adds the slabs of the following workgroups in
+// order and runs the normal epilogue.  Tails are computed first and heads last in every range, so an owner practically never
+// waits.  Hand-off as in the split-K reducer above (sc1 stores / relaxed agent ticket / sc1 loads, no fences).
+// =====================================================================================
+template <bool TA, bool TB>
+__device__ __forceinline__ void p8_segment(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, int K,
+                                           int m0, int n0, int M, int N, int t_begin, int nt, unsigned char* smem_raw, int wave,
+                                           int wr, int wc, int lane, f32x4 (&acc)[8][4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef DmaOperand<TA, 128, 512, 64> OpA;
+    typedef DmaOperand<TB, 128, 512, 64> OpB;
+    constexpr int HALF = 16384;
+    OpA opa; OpB opb;
+    opa.init(A, lda, m0, M, K, wave, lane);
+    opb.init(B, ldb, n0, N, K, wave, lane);
+    const int a_half = TA ? 256 : 128 * lda * 2;
+    const int b_half = TB ? 256 : 128 * ldb * 2;
+    f32x4 accb[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+    opa.issue(t_begin, smem_raw, wave, 0);
+    opa.issue(t_begin, smem_raw + HALF, wave, a_half);
+    opb.issue(t_begin, smem_raw + 2 * HALF, wave, 0);
+    opb.issue(t_begin, smem_raw + 3 * HALF, wave, b_half);
+    if (nt > 1) {
+        opb.issue(t_begin + 1, smem_raw + 65536 + 2 * HALF, wave, 0);
+        opb.issue(t_begin + 1, smem_raw + 65536 + 3 * HALF, wave, b_half);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OpB::NLOAD) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int t = 0; t < nt; t += 2) {
+        P8Tile<TA, TB, false, 0>::run(smem_raw, opa, opb, a_half, b_half, t, nt, t_begin, wave, wr, wc, lane, acc, accb, false);
+        if (t + 1 < nt)
+            P8Tile<TA, TB, false, 1>::run(smem_raw, opa, opb, a_half, b_half, t + 1, nt, t_begin, wave, wr, wc, lane, acc, accb, false);
+    }
+    if (wr == 0) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();            // every wave is done with the operand tiles
+#endif
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_p8sk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
+                                                                int ldb, int K, int tiles_m, int tiles_n, EpiArgs ep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nt = K / 64, P = gridDim.x, w = blockIdx.x;
+    const long I = (long)tiles_m * tiles_n * nt;
+    long it0 = I * w / P;
+    const long it1 = I * (w + 1) / P;
+    float alpha = ep.e.alpha;
+    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
+    constexpr int SLAB = 256 * 256 * 4;
+    __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(ep.e.splitk_ws, 0, P * SLAB, 0x00020000);
+    f32x4 acc[8][4];
+    while (it0 < it1) {
+        const int tile = (int)(it0 / nt), k0 = (int)(it0 % nt);
+        const int k1 = (int)((it1 - it0) < (long)(nt - k0) ? k0 + (it1 - it0) : nt);
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        const int m0 = tm * 256, n0 = tn * 256;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+        p8_segment<TA, TB>(A, lda, B, ldb, K, m0, n0, ep.M, ep.N, k0, k1 - k0, smem_raw, wave, wr, wc, lane, acc);
+        if (k0 != 0) {
+            // contributor: this workgroup's one slab (slot = its index), then a ticket on the tile
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { f32x4 f; u32x4 u; } x;
+                    x.f = acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(x.u, ws, w * SLAB + ((i * 4 + j) * 512 + tid) * 16, 0, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(ep.e.splitk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (k1 != nt) {
+                // owner of a tile other workgroups finish: they are w + 1 .. the workgroup holding the tile's last iteration
+                const long last_it = (long)(tile + 1) * nt - 1;
+                int wl = (int)(last_it * P / I);
+                while (I * (wl + 1) / P <= last_it) ++wl;
+                while (I * wl / P > last_it) --wl;
+                const int ncontrib = wl - w;
+                if (tid == 0) {
+                    while (__hip_atomic_load(ep.e.splitk_cnt + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ncontrib)
+                        __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(ep.e.splitk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int c = 1; c <= ncontrib; ++c) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            union { f32x4 f; u32x4 u; } x;
+                            x.u = __builtin_amdgcn_raw_buffer_load_b128(ws, (w + c) * SLAB + ((i * 4 + j) * 512 + tid) * 16, 0, 16);
+                            acc[i][j] += x.f;
+                        }
+                }
+            }
+            epilogue_tile<8, 4>(ep, acc, m0 + wr * 128, n0 + wc * 64, lane, alpha, smem_raw + wave * 8192);
+            __syncthreads();    // the transpose slices are the operand buffers of the next segment
+        }
+        it0 += k1 - k0;
+    }
+#endif
+}
+
+// =====================================================================================
 // fp32 kernel: 64x64x16 tile, 4 waves (2x2), each 32x32 = 2x2 tiles of 16x16x4
 // =====================================================================================
 constexpr int FM = 64, FN = 64, FK = 16, FLD = 68;
@@ -1463,6 +1592,22 @@ int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int 
     return ILVLM_OK;
 }
 
+constexpr int ILVLM_SK_GRID = 256;     // one workgroup per CU of an MI355X
+
+template <bool TA, bool TB>
+int launch_p8sk(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_p8sk_kernel<TA, TB>;
+    constexpr int bytes = 131072;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_p8sk: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
+    hipLaunchKernelGGL(kern, dim3(ILVLM_SK_GRID), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_p8sk");
+    return ILVLM_OK;
+}
+
 template <bool TA, bool TB>
 int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
                hipStream_t s) {
@@ -1589,7 +1734,22 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bool fast = (variant != 0 || epi->pool_out) && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
         // 8 = 256x256 phased kernel (one workgroup per CU): the tall GEMMs of the towers
-        if (fast && variant == 8 && M >= 256 && N >= 256) {
+        // A/B rule (ILVLM_GEMM_AUTO8=<K threshold>, off by default): send the store-type GEMMs with a narrow output and a deep
+        // reduction (N <= 768, K >= threshold: down-projection forward, up-projection / in-projection input gradients) to the
+        // 256x256 phased kernel.  They have only 90...150 tiles of 256x256, so it occupies that many CUs with one workgroup
+        // each and leaves the rest to the other streams: +1.1 %, +0.8 % and +0.0 % of the step in three same-box runs.
+        static const int auto8 = getenv("ILVLM_GEMM_AUTO8") ? atoi(getenv("ILVLM_GEMM_AUTO8")) : 0;
+        const bool pick8 = auto8 > 0 && variant == 5 && swap && N <= 768 && K >= auto8 && M >= 4096 && !epi->pool_out;
+        // variant 14 (A/B): the stream-K form of that kernel; needs the caller's slab workspace (epilogue splitk_* fields:
+        // 64 MiB of slabs, zeroed ticket counters) and at least two K-tiles of work per workgroup
+        if (fast && variant == 14 && swap && !trans_a && K % 64 == 0 && !epi->pool_out && slab_ws && epi->splitk_cnt &&
+            epi->splitk_ws_bytes >= (long)ILVLM_SK_GRID * 256 * 256 * 4 && epi->splitk_cnt_len >= ceil_div(M, 256) * ceil_div(N, 256) &&
+            (long)ceil_div(M, 256) * ceil_div(N, 256) * (K / 64) >= 2L * ILVLM_SK_GRID) {
+            ep.e.splitk_ws = slab_ws;
+            if (trans_b) return launch_p8sk<false, true>(a, lda, b, ldb, K, M, N, ep, s);
+            return launch_p8sk<false, false>(a, lda, b, ldb, K, M, N, ep, s);
+        }
+        if (fast && (variant == 8 || pick8) && M >= 256 && N >= 256) {
 #define ILVLM_P8(TA, TB)                                                                                 \
     return swap ? launch_p8<TA, TB, false>(a, lda, b, ldb, K, M, N, split_k, ep, s)                      \
                 : launch_p8<TA, TB, true>(a, lda, b, ldb, K, M, N, split_k, ep, s)
@@ -1663,7 +1823,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 13), "gemm_set_variant: 0 or 5 .. 13");
+    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 14), "gemm_set_variant: 0 or 5 .. 14");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }

@@ -654,6 +654,39 @@ def test_weight_gradient_gemm_at_full_size(M, N, K, split):
         assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(12800, 768, 3072, 0), (12800, 768, 2304, 1), (11319, 512, 2048, 0), (11319, 512, 1536, 1),
+                                      (4096, 512, 1536, 0)])
+def test_stream_k_phased_kernel_is_right_and_repeatable(M, N, K, tb):
+    """variant 14: the 256x256 phased kernel as a stream-K kernel (256 workgroups share tiles x K-tiles iterations equally;
+    tails go out as slabs, the workgroup holding k = 0 of a tile adds them and runs the epilogue): equal to an fp32 reference
+    through the residual / bias epilogue, bit-identical from launch to launch, ticket counters left at zero."""
+    ops = _ops()
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
+    ref = a.float() @ (w.float() if tb else w.float().t())
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    slab = (torch.empty(64 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(4096, dtype=torch.int32, device="cuda"))
+    slab[0].fill_(0xff)
+    want = ref + bias + res
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(a, w, out, trans_b=bool(tb), bias=bias, residual=res)            # default kernel
+    assert float((out - want).abs().max()) < 1e-5 * float(want.abs().max())
+    try:
+        ops.gemm_set_variant(14)
+        first = None
+        for it in range(6):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(a, w, out, trans_b=bool(tb), bias=bias, residual=res, slab=slab)
+            assert float((out - want).abs().max()) < 1e-5 * float(want.abs().max()), "launch %d" % it
+            if first is None:
+                first = out
+            else:
+                assert torch.equal(out, first)
+        assert int(slab[1].abs().sum()) == 0
+    finally:
+        ops.gemm_set_variant(5)
+
+
 @pytest.mark.parametrize("M,N,K,split", [(3072, 768, 12800, 3), (768, 3072, 12800, 3), (2304, 768, 12800, 4), (2048, 512, 11319, 6),
                                          (304, 200, 1000, 5), (128, 128, 256, 4), (1536, 512, 11319, 8)])
 def test_slab_split_k_weight_gradient_is_right_and_bit_reproducible(M, N, K, split):
