@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert handle.ilvlm_version() == 200
 
 
+def test_ctypes_table_has_the_headers_argument_counts():
+    """every prototype of include/ilvlm_hip.h against the ctypes argtypes table: same number of parameters (a missing or
+    extra argument would shift every pointer after it)"""
+    from ilvlm_amd import lib
+    text = open(os.path.join(ROOT, "include", "ilvlm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(ilvlm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(lib.SIGNATURES) <= set(protos)
+    for name, args in lib.SIGNATURES.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else len([x for x in params.split(",") if x.strip()])
+        assert n == len(args), "%s: header declares %d parameters, ctypes table has %d" % (name, n, len(args))
+
+
 def test_bad_arguments_are_rejected_without_a_launch():
     from ilvlm_amd import lib
     h = lib.load()
