@@ -156,25 +156,43 @@ class Fp8State:
         self.table = torch.tensor(table, dtype=torch.int32).to(dev)
         self.W8 = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
         self.W8T = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
-        self.steps = 0            # scale updates done; 0 = nothing observed yet
+        self.steps = 0            # training forwards begun = scale updates done; 0 = nothing observed yet
+        self.bwd_seen = 0         # backward passes observed (their gradient amaxes are what the e5m2 scales come from)
+        self.w_observed = False   # weight amaxes recorded once
         self.active = False       # False: observe only (bf16 GEMMs); True: fp8 GEMMs
 
+    def _quantize_weights(self, st):
+        ops.L.check(ops.L.load().ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
+                                                            self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
+                                                            self.amax.data_ptr(), st), "fp8_quantize_weights")
+
+    def _scale_update(self, st, pos):
+        ops.L.check(ops.L.load().ilvlm_fp8_scale_update(self.amax.data_ptr(), self.hist.data_ptr(), self.scale.data_ptr(),
+                                                        self.inv.data_ptr(), self.fmt_max.data_ptr(), self.n, self.HIST,
+                                                        pos, st), "fp8_scale_update")
+
     def begin_step(self, training):
-        """once per forward: activations / gradients of the previous step -> scales; weights re-quantised from the masters"""
-        lib = ops.L.load()
+        """Once per forward.  Only a TRAINING forward (gradients enabled) advances the delayed-scaling state: the amaxes the
+        previous step recorded enter the history, the scales follow, the weights are re-quantised.  A no-grad forward
+        (`encode_image`, `extract_*`, the data-parallel wrapper's constructor) advances nothing -- it would otherwise consume
+        the observe-only step with every activation / gradient amax still 0 and the first real step would quantise e5m2
+        gradients at scale 1, i.e. flush most of them to zero.  It only re-quantises the weights with the scales in force
+        (they may have been loaded or reset since); on the very first call the weight scales come from an observe pass whose
+        history slot the first training step rewrites.
+        fp8 GEMMs are switched on (`active`) once a training forward AND a backward have been observed, so that every
+        activation and every gradient slot has a non-empty history."""
         st = ops._stream()
-        if self.steps == 0:       # weights: observe their amax first so that the very first quantisation is scaled
-            ops.L.check(lib.ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
-                                                       self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
-                                                       self.amax.data_ptr(), st), "fp8_quantize_weights")
-        ops.L.check(lib.ilvlm_fp8_scale_update(self.amax.data_ptr(), self.hist.data_ptr(), self.scale.data_ptr(),
-                                               self.inv.data_ptr(), self.fmt_max.data_ptr(), self.n, self.HIST,
-                                               self.steps % self.HIST, st), "fp8_scale_update")
-        ops.L.check(lib.ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
-                                                   self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
-                                                   self.amax.data_ptr(), st), "fp8_quantize_weights")
-        self.active = self.steps >= 1          # activation / gradient slots have a history from the second step on
-        self.steps += 1
+        if not self.w_observed:   # weights: observe their amax first so that the very first quantisation is scaled
+            self._quantize_weights(st)
+            if not training:
+                self._scale_update(st, self.steps % self.HIST)
+            self.w_observed = True
+        if training:
+            self._scale_update(st, self.steps % self.HIST)
+        self._quantize_weights(st)
+        if training:
+            self.active = self.steps >= 1 and self.bwd_seen >= 1
+            self.steps += 1
 
     def s(self, key):
         i = self.slots[key]
@@ -248,7 +266,9 @@ class Engine:
         return self._side
 
     # ------------------------------------------------------------------ parameters
-    def prepare(self):
+    def prepare(self, training=False):
+        """Adopt / re-check the parameters before a forward.  `training`: a forward whose backward will run (gradients
+        enabled); only such a forward advances the fp8 delayed-scaling state (Fp8State.begin_step)."""
         if self.arena is None:
             self.arena = ParamArena(self.m, self.precision)
             self.arena.inactive = set(self.m.unused_parameter_names())
@@ -274,7 +294,7 @@ class Engine:
                 pres = ["visual.transformer.resblocks.%d." % i for i in range(self.cfg["v_layers"])] + \
                        ["encode_text.transformer.resblocks.%d." % i for i in range(self.cfg["t_layers"])]
                 self.fp8 = Fp8State(a, pres)
-            self.fp8.begin_step(True)
+            self.fp8.begin_step(bool(training))
         req = {n: p.requires_grad for n, p in a.named}
         if req != getattr(self, "req", None):
             self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots
@@ -379,8 +399,8 @@ class Engine:
             keep.append(dy)
             keep.append(x)       # x may be a temporary of the caller (the un-padded patch rows of a trainable conv1)
             keep.append(dy8)
-            ops._stream_override = wg.cuda_stream          # cheaper than entering a torch stream context per GEMM
-        try:
+        # thread-local launch-stream override: cheaper than entering a torch stream context per GEMM
+        with ops.stream_override(wg.cuda_stream if wg is not None else None):
             if self.req[wname] and dy8 is not None and x8 is not None and x8[0] is not None:
                 ops.gemm_fp8_wgrad(dy8, x8[0], self.Gr[wname].reshape(N, -1), self.fp8.s(pre + kg)[1], self.fp8.s(pre + x8[1])[1],
                                    split_k=ops.wgrad_split(N, K, M, 128), rowsum=self.Gr[bname] if fuse_b else None, slab=slab)
@@ -391,8 +411,6 @@ class Engine:
                          a_rowsum=self.Gr[bname] if fuse_b else None, slab=slab if self.T == torch.bfloat16 else None)
             if need_b and not fuse_b:
                 ops.colsum(dy, self.Gr[bname])
-        finally:
-            ops._stream_override = None
         if not need_dx:
             return None
         dx = _empty((M, K), self.T, dy)

@@ -5,6 +5,7 @@ down) and raise RuntimeError on any failure; there is no fallback path."""
 import ctypes as C
 import math
 import os
+import threading
 
 import torch
 
@@ -22,13 +23,45 @@ def torch_dtype(code):
     return torch.float32 if code == F32 else torch.bfloat16
 
 
-_stream_override = None     # raw stream handle: launches go there instead of the current stream (engine, wgrad stream)
+# Launch-stream override (raw stream handle): inside `with stream_override(h):` every launch of THIS thread goes to h
+# instead of torch's current stream -- the engine sends weight-gradient GEMMs to a companion stream that way, which is
+# cheaper than entering a torch stream context per GEMM.  Thread-local on purpose: ctypes releases the GIL during a launch,
+# and the prefetcher / checkpoint threads (solver.DevicePrefetcher) launch kernels of their own on their own streams; a
+# process-global switch would route those onto the weight-gradient stream, un-ordered against the copies they depend on.
+_tls = threading.local()
+
+
+class stream_override:
+    __slots__ = ("handle", "prev")
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "override", None)
+        _tls.override = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        _tls.override = self.prev
+        return False
+
+
+def _override():
+    return getattr(_tls, "override", None)
 
 
 def _stream():
-    if _stream_override is not None:
-        return _stream_override
+    s = getattr(_tls, "override", None)
+    if s is not None:
+        return s
     return torch.cuda.current_stream().cuda_stream
+
+
+def _event_stream():
+    """torch stream object matching _stream() (for event records of the GEMM profiler)"""
+    s = getattr(_tls, "override", None)
+    return torch.cuda.ExternalStream(s) if s is not None else torch.cuda.current_stream()
 
 
 def _p(t):
@@ -138,7 +171,7 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # the events go on the stream the kernel is launched on (a weight-gradient GEMM runs on the companion stream)
-        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        est = _event_stream()
         ev0.record(est)
     L.check(L.load().ilvlm_gemm(dt(a), int(trans_a), int(trans_b), m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb,
                                 out.data_ptr(), ldc, C.byref(epi), int(split_k), _stream()), "gemm")
@@ -171,7 +204,7 @@ def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual
     prof = _gemm_profiler
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        est = _event_stream()
         ev0.record(est)
     L.check(L.load().ilvlm_gemm(L.FP8_BF8A if a_e5m2 else L.FP8, 0, 0, m, n, k, a8.data_ptr(), a8.stride(0), b8.data_ptr(),
                                 b8.stride(0), out.data_ptr(), out.stride(0), C.byref(epi), 1, _stream()), "gemm(fp8)")
@@ -202,7 +235,7 @@ def gemm_fp8_wgrad(dy8, x8, out, scale_dy, scale_x, *, split_k=1, rowsum=None, K
     prof = _gemm_profiler
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        est = torch.cuda.ExternalStream(_stream_override) if _stream_override is not None else torch.cuda.current_stream()
+        est = _event_stream()
         ev0.record(est)
     L.check(L.load().ilvlm_gemm(L.FP8_BF8A, 1, 1, m, n, k, dy8.data_ptr(), dy8.stride(0), x8.data_ptr(), x8.stride(0),
                                 out.data_ptr(), out.stride(0), C.byref(epi), int(split_k), _stream()), "gemm(fp8 wgrad)")

@@ -21,6 +21,8 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, model, images, tokens, pad_mask, seq, *params):
         li, lt, saved = model._forward_impl(images, tokens, pad_mask, True, seq)
         ctx.model, ctx.saved, ctx.n = model, saved, len(params)
+        f8 = model._eng.fp8
+        ctx.fp8_active = None if f8 is None else f8.active     # the saved buffers have THIS mode's layout
         return li, lt
 
     @staticmethod
@@ -31,7 +33,17 @@ class _StepFn(torch.autograd.Function):
         li = saved["head"][9]
         dli = torch.zeros_like(li) if dli is None else dli
         dlt = torch.zeros_like(li) if dlt is None else dlt
-        ctx.model._backward_impl(saved, dli, dlt)
+        f8 = ctx.model._eng.fp8
+        if f8 is None:
+            ctx.model._backward_impl(saved, dli, dlt)
+        else:
+            # run the backward in the fp8 mode of ITS forward (another forward may have switched the state since)
+            now, f8.active = f8.active, ctx.fp8_active
+            try:
+                ctx.model._backward_impl(saved, dli, dlt)
+            finally:
+                f8.active = now
+            f8.bwd_seen += 1
         return (None,) * (5 + ctx.n)
 
 
@@ -93,12 +105,13 @@ class ContrastiveBase(nn.Module):
 
     def _run(self, images, texts):
         eng = self._eng
-        eng.prepare()
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        eng.prepare(training=training)
         dev = eng.arena.P.device
         if not images.is_cuda:
             raise RuntimeError("images must be on the GPU (the solver calls image.cuda())")
         params = [p for _, p in eng.arena.named]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if training:
             tokens, pad_mask, seq = self._text_inputs(texts, dev, want_seq=True)
             return _StepFn.apply(self, images, tokens, pad_mask, seq, *params)
         tokens, pad_mask = self._text_inputs(texts, dev)

@@ -340,7 +340,14 @@ class ClsSolver:
         self.stored_codebook = self.model.module.space_dict.data.clone()
 
     def keep_codebook_value(self):
-        self.model.module.space_dict.data.copy_(self.stored_codebook)
+        """Pin the codebook to its stored value (train_solver.py:214,553).  The write goes through `.data`, which neither the
+        version counters nor the storage check of Engine.prepare() see, and AdamW has just written the bf16 shadow of the
+        post-step codebook: without mark_dirty() the FDT score GEMM would keep reading the un-pinned values."""
+        m = self.model.module
+        m.space_dict.data.copy_(self.stored_codebook)
+        eng = getattr(m, "engine", None)
+        if eng is not None:
+            eng.mark_dirty()
 
     def _clamp_logit_scale(self):
         gc = self.config.grad_clip
