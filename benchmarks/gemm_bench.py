@@ -1,59 +1,60 @@
-"""Micro-benchmark of the bf16 GEMM variants on the shapes of one ViT-B/32 + text block at per-GPU batch 256
-(forward, dgrad, wgrad).  Interleaved rounds in one process; prints TFLOP/s per shape and variant."""
-import sys, os, time
+"""Micro-benchmark of the bf16 GEMM kernels on the shapes of one ViT-B/32 + text block at per-GPU batch 256
+(forward, dgrad, wgrad).  Interleaved rounds in one process, cold caches (a 512 MB write between launches, as inside a
+train step); prints TFLOP/s per shape for selector 5 (direct-to-LDS single-stage kernel everywhere) and 15 (default: the
+streaming kernel on a packed B operand for the store-type shapes, the two-stage ring for the weight gradients).  usage: gemm_bench.py [tag-substring] [--epi] [--wn 2|4 via ILVLM_PK_WN]"""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops
 
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
-for tag, M, E in (("vit", 12800, 768), ("txt", 19712, 512)):
+for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
     for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E)):
         SHAPES.append((tag + "." + name + ".fwd", 0, 0, M, n, k, False, 1))
         SHAPES.append((tag + "." + name + ".dgrad", 0, 1, M, k, n, False, 1))
         SHAPES.append((tag + "." + name + ".wgrad", 1, 1, n, k, M, True, ops.wgrad_split(n, k, M)))
-for (tag, M, N, K) in [("pk.qkv.fwd", 11319, 1536, 512), ("pk.out.fwd", 11319, 512, 512), ("pk.fc.fwd", 11319, 2048, 512),
-                       ("pk.proj.fwd", 11319, 512, 2048)]:
-    SHAPES.append((tag, 0, 0, M, N, K, False, 1))
 SHAPES.append(("fdt.img.scores", 0, 0, 12544, 4096, 512, False, 1))
 SHAPES.append(("fdt.txt.scores", 0, 0, 19712, 4096, 512, False, 1))
 
 
-FLUSH = None
-
-
-def run(variants=(5, 6, 7, 9), rounds=5, only=None):
-    global FLUSH
+def run(rounds=7, only=None, epi=False):
     torch.manual_seed(0)
-    FLUSH = torch.empty(128 * 1024 * 1024, device="cuda")
-    res = {}
+    flush = torch.empty(128 * 1024 * 1024, device="cuda")
+    tot = {5: 0.0, 15: 0.0}
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:
         if only and only not in tag:
             continue
         a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
         b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)
         out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else torch.bfloat16)
-        for v in variants:
-            ops.gemm_set_variant(v)
-            ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split)
-        torch.cuda.synchronize()
+        kw = {}
+        if epi and not acc:        # the MLP up-projection's epilogue: bias + QuickGELU with the pre-activation stored
+            kw = dict(bias=torch.randn(N, device="cuda"), aux=torch.empty(M, N, device="cuda", dtype=torch.bfloat16), act=1)
+        packed = None if acc else ops.gemm_pack_b(b, trans_b=bool(tb))
+        variants = (5, 15)
         best = {v: 1e9 for v in variants}
-        for r in range(rounds):
+        for r in range(rounds + 1):
             for v in variants:
                 ops.gemm_set_variant(v)
-                FLUSH.zero_()            # cold caches, as inside a train step
+                flush.zero_()            # cold caches, as inside a train step
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split)
+                ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split,
+                         b_packed=packed if v == 15 else None, **kw)
                 e1.record()
                 torch.cuda.synchronize()
-                best[v] = min(best[v], e0.elapsed_time(e1))
+                if r:
+                    best[v] = min(best[v], e0.elapsed_time(e1))
         fl = 2.0 * M * N * K
-        res[tag] = {v: fl / (best[v] * 1e-3) / 1e12 for v in variants}
+        for v in variants:
+            tot[v] += best[v]
         print("%-18s M=%6d N=%5d K=%6d split=%2d  " % (tag, M, N, K, split) +
-              "  ".join("v%d %7.1f TF/s (%6.1f us)" % (v, res[tag][v], best[v] * 1e3) for v in variants), flush=True)
-    ops.gemm_set_variant(5)
-    return res
+              "  ".join("v%d %7.1f TF/s (%6.1f us)" % (v, fl / (best[v] * 1e-3) / 1e12, best[v] * 1e3) for v in variants) +
+              "   x%.2f" % (best[5] / best[15]), flush=True)
+    ops.gemm_set_variant(15)
+    print("sum of best times: v5 %.1f us, v15 %.1f us" % (tot[5] * 1e3, tot[15] * 1e3))
 
 
 if __name__ == "__main__":
-    run(only=sys.argv[1] if len(sys.argv) > 1 else None)
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    run(only=args[0] if args else None, epi="--epi" in sys.argv)

@@ -6,15 +6,21 @@ import ilvlm_amd.lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libilvlm_hip_stamps.so")
 from ilvlm_amd import ops
 import numpy as np
-CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 5, 128, 128, 4), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 7, 256, 128, 8),
-         ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 5, 128, 128, 4), ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 5, 128, 128, 4)]
+WN = int(os.environ.get("ILVLM_PK_WN", "2"))
+CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 5, 128, 128, 4), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 15, 128, 64 * WN, WN),
+         ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 5, 128, 128, 4), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 15, 128, 64 * WN, WN),
+         ("pk.fc.fwd", 0, 0, 11319, 2048, 512, False, 1, 5, 128, 128, 4), ("pk.fc.fwd", 0, 0, 11319, 2048, 512, False, 1, 15, 128, 64 * WN, WN),
+         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 5, 128, 128, 4)]
 for (tag, ta, tb, M, N, K, acc, split, v, bm, bn, nw) in CASES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else torch.bfloat16)
     ops.gemm_set_variant(v)
+    packed = ops.gemm_pack_b(b, trans_b=bool(tb)) if v == 15 else None
+    flush = torch.empty(128 * 1024 * 1024, device="cuda")
     for _ in range(3):
-        ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split)
+        flush.zero_()
+        ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split, b_packed=packed)
     torch.cuda.synchronize()
     nb = min(4096, ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * split)
     print(tag)

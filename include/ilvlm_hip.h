@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ILVLM_VERSION 200 /* round 2 */
+#define ILVLM_VERSION 300 /* round 3 */
 
 enum { ILVLM_OK = 0, ILVLM_ERR_ARG = -1 };
 enum { ILVLM_F32 = 0, ILVLM_BF16 = 1,
@@ -111,19 +111,31 @@ typedef struct ilvlm_gemm_epilogue {
     long splitk_ws_bytes;
     int32_t* splitk_cnt;
     int splitk_cnt_len;
+    /* optional copy of the B operand in MFMA-fragment order (ilvlm_gemm_pack_b / ilvlm_pack_weights), N x K bf16 elements:
+     * store-type bf16 GEMMs with a K-contiguous A operand (trans_a = 0, accumulate = 0, no pool epilogue, K % 64 == 0,
+     * N % 16 == 0) then run the streaming kernel -- A through a two-deep LDS ring, B straight from the packed copy into
+     * registers in whole 1 KiB wave loads -- instead of the direct-to-LDS 128x128 kernel; bit-identical results
+     * (same MFMA sequence per output element).  B / ldb are ignored by that kernel but must still be valid. */
+    const void* b_packed;
 } ilvlm_gemm_epilogue;
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
-/* bf16 kernel selection (tuning / tests; process-wide atomic): 0 register-staged general kernel, 5 direct-to-LDS 128x128
- * (default), 6 direct-to-LDS 64x128 (K-contiguous A operand), 7 direct-to-LDS 256x128 with a 3-stage ring, 8 the 256x256
- * phased 8-wave kernel (one workgroup per CU), 9 direct-to-LDS 256x128 single stage, 10 / 11 the weight-gradient form with a
- * 2- / 3-deep operand ring (measured -3 % / -40 %), 12 the weight-gradient form with 128-deep K-tiles (+6..10 % alone at
- * the same split, -1.7 % inside the step), 13 a persistent 128x128 kernel for the store-type GEMMs that refills its operand
- * buffers for the next tile ahead of the epilogue stores (-2.5 % inside the step), 14 the stream-K form of the 256x256 phased
- * kernel (needs the splitk_* workspace of the epilogue: 64 MiB + zeroed counters; -10 % inside the step); all kept for A/B.  Shapes the direct-to-LDS kernels
- * cannot take (K % 64 != 0, ragged K-strided operands) always use the general kernel. */
+/* bf16 kernel selection (tuning / tests; process-wide atomic): 15 (default) the streaming kernel wherever the epilogue
+ * offers b_packed and the direct-to-LDS 128x128 kernel elsewhere; 5 always the direct-to-LDS 128x128 kernel (the A/B
+ * reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
+ * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
+/* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
+ * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
+ * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +
+ * 8 (l >> 4) + j], j = 0..7 -- the operand register image of v_mfma_f32_16x16x32_bf16.  N % 16 == 0, K % 32 == 0. */
+int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int ldb, void* packed, void* stream);
+/* The same for every GEMM weight of a flat bf16 parameter arena in one launch (nn.Linear weights [out, in] of the residual
+ * attention blocks; base_transformer.py:35-48): table = n_tiles x {arena offset / 64, rows, cols, r0, c0} int32, one entry
+ * per 64 x 64 tile of a weight (rows, cols and the offset multiples of 64).  fwd (same offsets) receives the trans_b = 0
+ * image of W (the forward product X W^T), bwd the trans_b = 1 image (the input gradient dY W). */
+int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, const int32_t* table, int n_tiles, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-5 affine; base_transformer.py:10-18, clip_fdt.py:86-92) ----
  * y[r,:] = (x[R,:] - mean) * rstd * gamma + beta, R = map(r) when in_group > 0 (row remap as above:
@@ -326,6 +338,11 @@ typedef struct ilvlm_block {
     long splitk_ws_bytes;
     int32_t* splitk_cnt;
     int splitk_cnt_len;
+    /* optional fragment-order copies of the four GEMM weights (ilvlm_pack_weights), bf16 mode: *_wp = forward image (the
+     * b_packed operand of x W^T), *_wpt = input-gradient image (of dY W).  With them the eight store-type GEMMs of the block
+     * run the streaming kernel (ilvlm_gemm_epilogue.b_packed); NULL = the direct-to-LDS kernel on the row-major weights. */
+    const void *in_wp, *out_wp, *fc_wp, *proj_wp;
+    const void *in_wpt, *out_wpt, *fc_wpt, *proj_wpt;
 } ilvlm_block;
 long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L);
 long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);

@@ -368,6 +368,20 @@ __device__ __forceinline__ unsigned long long stamp() {
 // 256x128 / 8 / 3 (one workgroup per CU, K-tile t+1 / t+2 in flight during the MFMAs of tile t).
 // =====================================================================================
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types exist in the device pass only
+typedef int pk_i32x4 __attribute__((ext_vector_type(4)));
+
+// buffer descriptor as four SGPR words for the inline-asm loads (raw buffer, 32-bit range-checked offsets: what lies
+// past num_bytes reads as zero)
+__device__ __forceinline__ pk_i32x4 pk_rsrc(const void* base, long num_bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    pk_i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    r[2] = __builtin_amdgcn_readfirstlane(num_bytes > 0x7fffffffL ? 0x7fffffff : (int)num_bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
 template <bool TR, int ROWS, int NTHREADS, int BKT>
 struct DmaOperand {
     static constexpr int NLOAD = ROWS * BKT * 2 / (NTHREADS * 16);   // loads per thread per K-tile
@@ -375,7 +389,7 @@ struct DmaOperand {
     // the row only modulo 8, so one per-lane offset plus a scalar step serves all loads (register budget of the
     // 256x128 tile); K-strided operands keep one offset per load
     static constexpr int NVOFF = TR ? NLOAD : 1;
-    __amdgpu_buffer_rsrc_t rs;
+    pk_i32x4 rs;
     int voff[NVOFF];
     int jstep;
     int tile_off;    // byte offset of this workgroup's tile at k = 0
@@ -383,8 +397,7 @@ struct DmaOperand {
 
     __device__ __forceinline__ void init(const bf16* base, int ld, int r0, int R, int K, int wave, int lane) {
         const long elems = !TR ? (long)(R - 1) * ld + K : (long)(K - 1) * ld + R;
-        const long bytes = elems * 2;
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+        rs = pk_rsrc(base, elems * 2);
         jstep = !TR ? (BKT == 64 ? 8 : 16) * ld * 2 : 0;
 #pragma unroll
         for (int j = 0; j < NVOFF; ++j) {
@@ -404,12 +417,38 @@ struct DmaOperand {
         tile_off = !TR ? r0 * ld * 2 : r0 * 2;
         k_step = !TR ? BKT * 2 : BKT * ld * 2;
     }
+    // The loads are inline asm on purpose.  hipcc puts an `s_waitcnt vmcnt(0)` in front of the first ds_read that follows an
+    // LDS-DMA *builtin* (it must assume the read aliases the pending LDS write), which drains a prefetched K-tile right after
+    // it was issued: every multi-stage form of this kernel measured in rounds 1-2 was silently single-stage.  In asm the
+    // compiler sees no memory dependence; every wait of the main loop is placed by hand (s_waitcnt vmcnt + barrier in front
+    // of the reads of a stage, ILVLM_WG_BARRIER).  M0 (the LDS destination) is written and read inside the statement; the
+    // instruction between an M0 write and the load is the wait state that pair needs.
     __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
+        static_assert(NLOAD == 4, "four 1 KiB pieces per wave and operand (128-row operand, 256 threads)");
         const int soff = tile_off + t * k_step + extra;
-#pragma unroll
-        for (int j = 0; j < NLOAD; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
-                                                     16, voff[TR ? j : 0], soff + (TR ? 0 : j * jstep), 0, 0);
+        const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)tile + wave * (NLOAD * 1024);
+        const pk_i32x4 r4 = rs;
+        if constexpr (TR) {
+            asm volatile(
+                "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v3], %[rs], %[so] offen lds"
+                :
+                : [v0] "v"(voff[0]), [v1] "v"(voff[TR ? 1 : 0]), [v2] "v"(voff[TR ? 2 : 0]), [v3] "v"(voff[TR ? 3 : 0]), [rs] "s"(r4),
+                  [so] "s"(soff), [lds] "s"(lds)
+                : "memory", "scc");
+        } else {
+            int tmp;
+            asm volatile(
+                "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[so]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds"
+                : [t] "=&s"(tmp)
+                : [v0] "v"(voff[0]), [rs] "s"(r4), [so] "s"(soff), [js] "s"(jstep), [lds] "s"(lds)
+                : "memory", "scc");
+        }
     }
 };
 
@@ -425,12 +464,11 @@ struct DmaOperandTr8 {
     static_assert(ROWS == 128, "128-byte k-rows");
     static constexpr int KT = 128;
     static constexpr int NLOAD = KT * ROWS / (NTHREADS * 16);
-    __amdgpu_buffer_rsrc_t rs;
+    pk_i32x4 rs;
     int voff[NLOAD];
     int tile_off, k_step;
     __device__ __forceinline__ void init(const bf16* base, int ld, int r0, int R, int K, int wave, int lane) {
-        const long bytes = (long)(K - 1) * ld + R;
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+        rs = pk_rsrc(base, (long)(K - 1) * ld + R);
 #pragma unroll
         for (int j = 0; j < NLOAD; ++j) {
             const int s = (wave * NLOAD + j) * 64 + lane;
@@ -440,12 +478,18 @@ struct DmaOperandTr8 {
         tile_off = r0;
         k_step = KT * ld;
     }
-    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
+    __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {     // asm: see DmaOperand
+        static_assert(NLOAD == 4, "four 1 KiB pieces per wave and operand");
         const int soff = tile_off + t * k_step + extra;
-#pragma unroll
-        for (int j = 0; j < NLOAD; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + (wave * NLOAD + j) * 1024),
-                                                     16, voff[j], soff, 0, 0);
+        const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)tile + wave * (NLOAD * 1024);
+        asm volatile(
+            "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v3], %[rs], %[so] offen lds"
+            :
+            : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [rs] "s"(rs), [so] "s"(soff), [lds] "s"(lds)
+            : "memory", "scc");
     }
 };
 
@@ -996,474 +1040,263 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 }
 
 // =====================================================================================
-// Persistent form of the 128x128x64 kernel for the store-type GEMMs (forward, input gradient; variant 13, A/B).
-// What the round-2 measurements say bounds the default kernel on the step's K = 512...768 shapes is not the K-loop (it runs
-// at the L2->LDS ceiling) but that a workgroup slot moves operand bytes only about half of its lifetime: first-tile latency
-// before, epilogue after.  Here a workgroup walks tiles v = blockIdx.x, + gridDim.x, ...; when the K-loop of a tile ends it
-// issues the FIRST K-tile of its next tile and only then runs the epilogue, which transposes through 4 KiB per wave BEHIND
-// the operand buffers (16-row passes) -- the refill lands while the stores drain.  48 KiB of LDS: three workgroups per CU.
+// bf16 "streaming" kernel (round 3): store-type GEMMs C[M,N] = A[M,K] . Bop[N,K]^T whose B operand is a WEIGHT, i.e. can be
+// kept pre-packed in MFMA fragment order (ilvlm_gemm_pack_b): the forward products and input gradients of the towers.
+//
+// What bounded the direct-to-LDS kernel above (benchmarks/micro/l2_paths.hip):
+//   * the vector-memory path of a CU delivers 64 B/clk from L2 by LDS-DMA and by VGPR loads alike (130-139 GB/s per CU,
+//     34 TB/s chip) -- the 61 GB/s per CU that kernel reaches is its issue -> wait -> compute serialisation (a K-tile period
+//     is load latency PLUS compute), not a ceiling of the DMA path;
+//   * it cannot double-buffer: 2 x 32 KiB x 4 workgroups exceeds the 160 KiB of LDS, and with fewer workgroups the bytes in
+//     flight per CU stay the same;
+//   * and the multi-stage variants of rounds 1-2 never actually pipelined: hipcc puts an `s_waitcnt vmcnt(0)` in front of the
+//     first ds_read that follows an LDS-DMA *builtin* (it must assume the read aliases the pending LDS write), so the
+//     prefetched tile was drained right after it was issued.
+// Design:
+//   * only A (activations) goes through LDS: 128 rows x 64 k = 16 KiB per stage, TWO stages = 32 KiB per workgroup, so four
+//     workgroups per CU double-buffer inside the same LDS budget that gave the old kernel one stage;
+//   * B goes global -> VGPR directly: the packed copy makes every wave load one contiguous KiB (fragment-shaped loads from
+//     the row-major weight run at 38 GB/s per CU, a quarter of the rate), a wave owns 64 output columns and nobody else
+//     in the workgroup needs them, and the registers double-buffer B (K-tile t+1 lands while t is multiplied);
+//   * a wave owns 128 rows x 64 columns (8 x 4 accumulator tiles, 2 waves per SIMD): half the LDS fragment reads per
+//     FLOP of the 64 x 64 wave tiles; WN waves side by side: workgroup tile 128 x (64 WN);
+//   * every load of the main loop is inline asm and every wait is placed by hand (one `s_waitcnt vmcnt(0)` + ONE barrier per
+//     K-tile, both at the top of the step, when the loads waited for have had a whole compute phase to land):
+//         step t:  vmcnt(0); barrier            A(t) of every wave is in LDS, B(t) in registers; stage (t+1)&1 is free
+//                  issue A(t+1) -> stage (t+1)&1 ; issue B(t+1) -> the other register set
+//                  16 ds_read_b128 + 64 MFMA on stage t&1 and B(t)
+//     RAW: a wave's own pieces are retired by its vmcnt(0), everyone else's by the barrier behind it.  WAR: the DMA into
+//     stage (t+1)&1 is issued behind the barrier of step t, which every wave passes only after the last fragment read of
+//     step t-1 has returned (lgkmcnt(0) in front of the barrier).  B registers: VMEM writes them after the MFMAs that read
+//     them have issued (in-order issue).
+// Same MFMA sequence per output element as the direct-to-LDS kernel: results are bit-identical.
 // =====================================================================================
-template <bool TA, bool TB, int FP8 = 0>
-__global__ __launch_bounds__(256, 3) void gemm_bf16_persist_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                                   int ldb, int K, int tiles_m, int tiles_n, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int DBM = 128, DBN = 128, BKT = 64, NT = 256, TI = 4, TJ = 4, A_BYTES = DBM * BKT * 2, OPER = 2 * A_BYTES;
-    typedef DmaOperand<TA, DBM, NT, BKT> OpA;
-    typedef DmaOperand<TB, DBN, NT, BKT> OpB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = tiles_m * tiles_n, nt = K / BKT;
-    int v = blockIdx.x;                       // gridDim.x is a multiple of 8: every tile of this workgroup maps to its own XCD
-    if (v >= ntiles) return;
-    float alpha = ep.e.alpha;
-    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
-    OpA opa; OpB opb;
-    int wg = xcd_remap(v, ntiles);
-    int tn = wg % tiles_n, tm = wg / tiles_n;
-    opa.init(A, lda, tm * DBM, ep.M, K, wave, lane);
-    opb.init(B, ldb, tn * DBN, ep.N, K, wave, lane);
-    opa.issue(0, smem_raw, wave);
-    opb.issue(0, smem_raw + A_BYTES, wave);
-    f32x4 acc[TI][TJ];
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-        for (int t = 0; t < nt; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ILVLM_WG_BARRIER();
-            const unsigned char* as = smem_raw;
-            const unsigned char* bs = smem_raw + A_BYTES;
-            if constexpr (FP8 != 0) {         // fp8 operands, two per bf16 slot: the block-scaled MFMA with unit scales (see above)
-                typedef int v8i __attribute__((ext_vector_type(8)));
-                union F8 { struct { bf16x8 lo, hi; } h; v8i v; };
-                F8 fb8[TJ];
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    fb8[j].h.lo = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, 0, lane);
-                    fb8[j].h.hi = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, 32, lane);
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    F8 fa8;
-                    fa8.h.lo = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, 0, lane);
-                    fa8.h.hi = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, 32, lane);
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j].v, fa8.v, acc[i][j], 0, FP8 == 2 ? 1 : 0, 0,
-                                                                                     0x7f7f7f7f, 0, 0x7f7f7f7f);
-                }
-            } else
-#pragma unroll
-            for (int ks = 0; ks < BKT / 32; ++ks) {
-                bf16x8 fa[TI], fb[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM, BKT>(as, wm * 64 + i * 16, ks * 32, lane);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN, BKT>(bs, wn * 64 + j * 16, ks * 32, lane);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
-            ILVLM_WG_BARRIER();               // every wave is done with the tile before it is overwritten
-            if (t + 1 < nt) {
-                opa.issue(t + 1, smem_raw, wave);
-                opb.issue(t + 1, smem_raw + A_BYTES, wave);
-            }
-        }
-        const int mw = tm * DBM + wm * 64, nw = tn * DBN + wn * 64;
-        const int vn = v + gridDim.x;
-        if (vn < ntiles) {                    // refill for the next tile first, then the epilogue of this one
-            wg = xcd_remap(vn, ntiles);
-            tn = wg % tiles_n; tm = wg / tiles_n;
-            opa.init(A, lda, tm * DBM, ep.M, K, wave, lane);
-            opb.init(B, ldb, tn * DBN, ep.N, K, wave, lane);
-            opa.issue(0, smem_raw, wave);
-            opb.issue(0, smem_raw + A_BYTES, wave);
-        }
-        epilogue_tile<TI, TJ, 1>(ep, acc, mw, nw, lane, alpha, smem_raw + OPER + wave * 4096);
-        if (vn >= ntiles) break;
-        v = vn;
+// NP LDS-DMA pieces (1 KiB each: 8 operand rows x 128 B) of one wave: piece j lands at lds + 1024 j and reads 8 rows
+// further down (soffset + j * jstep).  M0 is written and read inside the one statement; the s_add between an M0 write and
+// the load is the wait state that pair needs.
+// `ok` == 0 skips the loads INSIDE the statement (a scalar branch): the compiler sees straight-line code, which keeps the
+// accumulators of the loop in place (a branch around the statement gave phi webs, copies and spills).
+template <int NP>
+__device__ __forceinline__ void pk_dma(pk_i32x4 rs, int voff, int soff, int jstep, unsigned lds, int ok) {
+    int t;
+#define PK_DMA_NEXT "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[vo], %[rs], %[t] offen lds\n\t"
+    if constexpr (NP == 8) {
+        asm volatile(
+            "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lpk_dma_skip%=\n\t"
+            "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[soff]\n\tbuffer_load_dwordx4 %[vo], %[rs], %[t] offen lds\n\t"
+            PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT
+            ".Lpk_dma_skip%=:"
+            : [t] "=&s"(t)
+            : [vo] "v"(voff), [rs] "s"(rs), [soff] "s"(soff), [js] "s"(jstep), [lds] "s"(lds), [ok] "s"(ok)
+            : "memory", "scc");
+    } else {
+        static_assert(NP == 4, "8 (two waves) or 4 (four waves) pieces per wave");
+        asm volatile(
+            "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lpk_dma_skip%=\n\t"
+            "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[soff]\n\tbuffer_load_dwordx4 %[vo], %[rs], %[t] offen lds\n\t"
+            PK_DMA_NEXT PK_DMA_NEXT PK_DMA_NEXT
+            ".Lpk_dma_skip%=:"
+            : [t] "=&s"(t)
+            : [vo] "v"(voff), [rs] "s"(rs), [soff] "s"(soff), [js] "s"(jstep), [lds] "s"(lds), [ok] "s"(ok)
+            : "memory", "scc");
     }
-#endif
+#undef PK_DMA_NEXT
 }
 
-// =====================================================================================
-// bf16 "phased" kernel: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), one workgroup per CU, 128 KiB of LDS =
-// two K-tile buffers of four 16 KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255).
-//
-// A 256x256 tile needs half the L2->LDS bytes per FLOP of the 128x128 kernel above (whose operand DMA and MFMA time
-// per K-tile are equal at the CU's 64 B/clk, so neither can be hidden behind the other).  The K-tile is cut into four
-// phases of {LOAD section: fragment ds_reads of one quadrant's operands + the DMA of one half-tile of a later K-tile;
-// COMPUTE section: 16 MFMAs = one 64x32 quadrant of the wave's 128x64 output x K = 64}, every section closed by a
-// workgroup barrier.  Waves 4-7 (the second wave of every SIMD) run one section behind waves 0-3, so on each SIMD one
-// wave's MFMAs cover the other's LDS reads and DMA issue.  DMA stays in flight across barriers behind a counted vmcnt.
-//
-// Schedule of K-tile t (buffer t & 1), wave (wr, wc): A half wr, B half wc >> 1, columns 64 (wc & 1) .. +63
-//   L1  read A rows 0-63 (8) + B cols 0-31 (4)     C1  acc[0..3][0..1], DMA A0(t+1) between the MFMAs
-//   L2  read B cols 32-63 (4)                      C2  acc[0..3][2..3], DMA A1(t+1)
-//   L3  read A rows 64-127 (8)                     C3  acc[4..7][2..3], DMA B0(t+2)
-//   L4  vmcnt: K-tile t+1 landed                   C4  acc[4..7][0..1], DMA B1(t+2)   (B cols 0-31 kept in registers)
-// Hazards, counted in sections (a wave of the late group runs section s one barrier interval after the early group):
-//   RAW  every wave retires its own pieces of K-tile t+1 with the vmcnt of L4(t); the first read of that buffer is in
-//        L1(t+1), two sections later, i.e. behind a barrier that every wave passed after its wait.
-//   WAR  a half-tile is re-filled two or more sections after the section that read it last, and every LOAD section drains
-//        its own ds_reads (lgkmcnt(0)) in front of its closing barrier: B halves are read last in L2 and re-filled from
-//        C3 on, A halves are read last in L3 and re-filled in C1 / C2 of the next K-tile.
-// =====================================================================================
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ILVLM_SECTION_END()                                     \
-    do {                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-        __builtin_amdgcn_sched_barrier(0);                      \
-        __builtin_amdgcn_s_barrier();                           \
-        __builtin_amdgcn_sched_barrier(0);                      \
-    } while (0)
+// the eight B fragments of a wave's K-tile (4 column tiles x 2 k-steps) from the packed copy: whole-KiB loads, the k-step
+// in the instruction offset.  Early-clobber outputs: the first load may write before the last has read its operands.
+// The registers are NOT valid behind this statement -- only behind the caller's s_waitcnt + pk_landed().
+__device__ __forceinline__ void pk_load_b(bf16x8 (&b)[4][2], pk_i32x4 rs, int voff, int s0, int s1, int s2, int s3, int ok) {
+    asm volatile(
+        "s_cmp_eq_u32 %14, 0\n\ts_cbranch_scc1 .Lpk_b_skip%=\n\t"
+        "buffer_load_dwordx4 %0, %8, %9, %10 offen\n\t"
+        "buffer_load_dwordx4 %1, %8, %9, %10 offen offset:1024\n\t"
+        "buffer_load_dwordx4 %2, %8, %9, %11 offen\n\t"
+        "buffer_load_dwordx4 %3, %8, %9, %11 offen offset:1024\n\t"
+        "buffer_load_dwordx4 %4, %8, %9, %12 offen\n\t"
+        "buffer_load_dwordx4 %5, %8, %9, %12 offen offset:1024\n\t"
+        "buffer_load_dwordx4 %6, %8, %9, %13 offen\n\t"
+        "buffer_load_dwordx4 %7, %8, %9, %13 offen offset:1024\n\t"
+        ".Lpk_b_skip%=:"
+        : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[1][0]), "=&v"(b[1][1]), "=&v"(b[2][0]), "=&v"(b[2][1]), "=&v"(b[3][0]),
+          "=&v"(b[3][1])
+        : "v"(voff), "s"(rs), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(ok)
+        : "memory", "scc");
+}
+// the compiler sees the registers (re)defined HERE, so no consumer can be scheduled above the wait in front of it
+__device__ __forceinline__ void pk_landed(bf16x8 (&b)[4][2]) {
+    asm volatile("" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]),
+                 "+v"(b[3][1]));
+}
 
-template <bool TA, bool TB, bool ACC, int PB>
-struct P8Tile {
-    typedef DmaOperand<TA, 128, 512, 64> OpA;
-    typedef DmaOperand<TB, 128, 512, 64> OpB;
-    static constexpr int HALF = 16384, BUF = 65536;
-
-    // 16 MFMAs of one quadrant; the DMA of one half-tile is issued between them (an LDS-DMA instruction costs the issuing
-    // wave 100-185 cycles next to LDS reads but ~60 among MFMAs, which keep executing while it issues)
-    template <class Op>
-    static __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const int i0, const int j0, bf16x8 (&fa)[4][2],
-                                                    bf16x8 (&fb)[2][2], bool dma, const Op& op, int tile_t,
-                                                    unsigned char* dst, int wave, int extra) {
-        __builtin_amdgcn_s_setprio(1);
-#if ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 4
+// 64 MFMAs of one K-tile: A fragments from the LDS stage, B fragments from registers (C^T fragments as everywhere else:
+// a lane owns output row (l & 15) and 4 consecutive columns)
+__device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1]));
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[j][0]), "v"(fb[j][1]));
-#else
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 fa = p8_frag<false, 128, 64>(as, i * 16, ks * 32, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[i0 + i][j0 + j], 0, 0, 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if ILVLM_GEMM_ABLATE != 2
-        if (dma) op.issue(tile_t, dst, wave, extra);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if !(ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][1], acc[i0 + i][j0 + j], 0, 0, 0);
-#endif
-        __builtin_amdgcn_s_setprio(0);
-    }
-
-    // one K-tile (t = index within this workgroup's K range, nt = their number)
-    static __device__ __forceinline__ void run(unsigned char* smem, const OpA& opa, const OpB& opb, int a_half, int b_half,
-                                               int t, int nt, int t_begin, int wave, int wr, int wc, int lane,
-                                               f32x4 (&acc)[8][4], f32x4 (&accb)[2], bool rowsum) {
-        unsigned char* cur = smem + PB * BUF;
-        unsigned char* nxt = smem + (PB ^ 1) * BUF;
-        const unsigned char* aT = cur + wr * HALF;
-        const unsigned char* bT = cur + 2 * HALF + (wc >> 1) * HALF;
-        const int bcol = (wc & 1) * 64;
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-        bf16x8 fa[4][2], fbl[2][2], fbr[2][2];
-#if ILVLM_GEMM_ABLATE == 1 || ILVLM_GEMM_ABLATE == 5
-#define P8_FRAG(TR, tile, r16, k32) ones
-#else
-#define P8_FRAG(TR, tile, r16, k32) p8_frag<TR, 128, 64>(tile, r16, k32, lane)
-#endif
-        // ---- L1
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbl[j][ks] = P8_FRAG(TB, bT, bcol + j * 16, ks * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, i * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C1
-        quadrant(acc, 0, 0, fa, fbl, more1, opa, t_begin + t + 1, nxt, wave, 0);
-        if (ACC && rowsum) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
-                accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[0], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], fa, acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L2
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbr[j][ks] = P8_FRAG(TB, bT, bcol + 32 + j * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C2
-        quadrant(acc, 0, 2, fa, fbr, more1, opa, t_begin + t + 1, nxt + HALF, wave, a_half);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L3
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, 64 + i * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C3
-        quadrant(acc, 4, 2, fa, fbr, more2, opb, t_begin + t + 2, cur + 2 * HALF, wave, 0);
-        if (ACC && rowsum) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
-                accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[1], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L4: every piece of K-tile t+1 this wave issued has landed (B0(t+2), issued in C3, may still be in flight)
-        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OpB::NLOAD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ILVLM_SECTION_END();
-        // ---- C4
-        quadrant(acc, 4, 0, fa, fbl, more2, opb, t_begin + t + 2, cur + 3 * HALF, wave, b_half);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
-
+}
 #endif
 
-template <bool TA, bool TB, bool ACC>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                              int ldb, int K, int tiles_m, int tiles_n, int split_k,
-                                                              EpiArgs ep) {
+template <int WN>
+__global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
+                                                                  int K, int tiles_m, int tiles_n, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef DmaOperand<TA, 128, 512, 64> OpA;
-    typedef DmaOperand<TB, 128, 512, 64> OpB;
-    constexpr int HALF = 16384;
+    constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
+    constexpr int STAGE = 128 * 64 * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int nwg = tiles_m * tiles_n * split_k;
-    int wg = xcd_remap(blockIdx.x, nwg);
-    const int tn = wg % tiles_n; wg /= tiles_n;
-    int z, tm;
-    if (ACC) { tm = wg % tiles_m; z = wg / tiles_m; }       // K-slice major (see gemm_bf16_dma_kernel)
-    else { z = wg % split_k; tm = wg / split_k; }
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nt_total = (K + 63) / 64;
-    const int per = (nt_total + split_k - 1) / split_k;
-    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
-    if (t_begin >= t_end) return;
-    const int nt = t_end - t_begin;
+    int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tn = wg % tiles_n, tm = wg / tiles_n;
+    if (ep.tile_group > 0) {            // L2 blocking of the tile walk, as in gemm_bf16_dma_kernel
+        const int idx = wg, Hb = (tiles_m + ep.tile_bands - 1) / ep.tile_bands, G = ep.tile_group;
+        const int band = idx / (Hb * tiles_n), hb = min(Hb, tiles_m - band * Hb);
+        const int r = idx - band * Hb * tiles_n, full = tiles_n / G;
+        int g, gw, rr;
+        if (r < full * hb * G) { g = r / (hb * G); gw = G; rr = r - g * hb * G; }
+        else { g = full; gw = tiles_n - full * G; rr = r - full * hb * G; }
+        tm = band * Hb + rr / gw;
+        tn = g * G + rr % gw;
+    }
+    const int m0 = tm * 128, n0 = tn * (64 * WN);
+    const int nt = K >> 6;
 
-    OpA opa; OpB opb;
-    opa.init(A, lda, m0, ep.M, K, wave, lane);
-    opb.init(B, ldb, n0, ep.N, K, wave, lane);
-    const int a_half = TA ? 256 : 128 * lda * 2;      // byte offset of operand rows 128.. within the tile
-    const int b_half = TB ? 256 : 128 * ldb * 2;
+    // A: per-lane source offset of piece 0 (rows 8 (wave NP) + (lane >> 3), 16-byte chunk (lane & 7) ^ (row & 7)); pieces
+    // step 8 rows, which leaves the swizzle unchanged
+    const pk_i32x4 rsa = pk_rsrc(A, ((long)(ep.M - 1) * lda + K) * 2);
+    const int arow = wave * NP * 8 + (lane >> 3);
+    const int a_voff = (arow * lda + (((lane & 7) ^ (arow & 7)) << 3)) * 2;
+    const int a_jstep = 8 * lda * 2;
+    int a_soff = m0 * lda * 2;                                       // + 128 bytes per K-tile
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_raw + wave * NP * 1024;
+    // B: this wave's 4 column tiles of 16; block (n / 16, k / 32) is KiB number (n / 16) * (K / 32) + k / 32
+    const pk_i32x4 rsb = pk_rsrc(Bp, (long)ep.N * K * 2);
+    const int b_voff = lane * 16;
+    const int kb = (K >> 5) << 10;                                   // bytes per column tile
+    int bs0 = ((n0 >> 4) + wave * 4) * kb, bs1 = bs0 + kb, bs2 = bs1 + kb, bs3 = bs2 + kb;     // + 2 KiB per K-tile
 
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    f32x4 accb[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
-    const bool rowsum = ACC && ep.e.a_rowsum != nullptr && tn == 0;
+    bf16x8 b0[4][2], b1[4][2];
 
-    // prologue: K-tile 0 complete, B halves of K-tile 1
-    opa.issue(t_begin, smem_raw, wave, 0);
-    opa.issue(t_begin, smem_raw + HALF, wave, a_half);
-    opb.issue(t_begin, smem_raw + 2 * HALF, wave, 0);
-    opb.issue(t_begin, smem_raw + 3 * HALF, wave, b_half);
-    if (nt > 1) {
-        opb.issue(t_begin + 1, smem_raw + 65536 + 2 * HALF, wave, 0);
-        opb.issue(t_begin + 1, smem_raw + 65536 + 3 * HALF, wave, b_half);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OpB::NLOAD) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // one K-tile: wait for what was issued a step ago, barrier, prefetch the next K-tile (skipped inside the asm when there
+    // is none), multiply.  Straight-line code on purpose (see pk_dma).
+#ifdef ILVLM_GEMM_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+    STAMP(t_start);
+#define PK_KEEP() asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][3]))
+#else
+#define PK_KEEP()
+#endif
+#define PK_STEP(CUR_STAGE, NXT_STAGE, BCUR, BNXT, MORE)                                   \
+    do {                                                                                  \
+        STAMP(p0);                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+        pk_landed(BCUR);                                                                  \
+        STAMP(p1);                                                                        \
+        ILVLM_WG_BARRIER();                                                               \
+        STAMP(p2);                                                                        \
+        a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;               \
+        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0 + (NXT_STAGE) * STAGE, MORE);       \
+        pk_load_b(BNXT, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                           \
+        STAMP(p3);                                                                        \
+        pk_compute(acc, smem_raw + (CUR_STAGE) * STAGE, BCUR, lane);                      \
+        PK_KEEP();                                                                        \
+        STAMP(p4);                                                                        \
+        STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_issue, p2, p3); STAMP_ADD(c_comp, p3, p4); \
+    } while (0)
+    pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
+    pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
+    const int pairs = nt >> 1;
+    for (int tp = 0; tp < pairs; ++tp) {
+        PK_STEP(0, 1, b0, b1, 1);
+        PK_STEP(1, 0, b1, b0, __builtin_amdgcn_readfirstlane(2 * tp + 2 < nt ? 1 : 0));
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) {                                     // the second wave of every SIMD runs one section behind
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int t = 0; t < nt; t += 2) {
-        P8Tile<TA, TB, ACC, 0>::run(smem_raw, opa, opb, a_half, b_half, t, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
-        if (t + 1 < nt)
-            P8Tile<TA, TB, ACC, 1>::run(smem_raw, opa, opb, a_half, b_half, t + 1, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
-    }
-    if (wr == 0) {
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    if (nt & 1) PK_STEP(0, 1, b0, b1, 0);
+#undef PK_STEP
+#undef PK_KEEP
+#ifdef ILVLM_GEMM_STAMPS
+    STAMP(t_loop_end);
+#endif
 
     float alpha = ep.e.alpha;
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
-    __syncthreads();            // every wave is done with the operand tiles before the fragments go through the same LDS
-#if ILVLM_GEMM_ABLATE == 3
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
-    if (!ACC) {
-        epilogue_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
-    } else {
-        epilogue_acc_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
-        if (rowsum && lane < 16) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = mw + (h * 4 + wc) * 16 + lane;
-                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[h][0]);
-            }
-        }
+    if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
+    // every wave is done reading the operand stages before any wave transposes its fragments through the same LDS
+    __syncthreads();
+    epilogue_tile<8, 4>(ep, acc, m0, n0 + wave * 64, lane, alpha, smem_raw + wave * 8192);
+#ifdef ILVLM_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_end_);
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 6;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_loop_end - t_start; o[5] = t_end_ - t_loop_end;
     }
+#endif
 #endif
 }
 
-// =====================================================================================
-// Stream-K form of the phased 256x256 kernel for the store-type GEMMs with few tiles and a deep K (N <= 768, K >= 1536:
-// 150 / 90 tiles for 256 CUs; variant 14 / ILVLM_GEMM_AUTO8).  One workgroup per CU; the tiles x K-tiles iterations are cut
-// into gridDim.x equal contiguous ranges.  A range starts inside a tile (its TAIL part: the partial sums go out at once as
-// a slab -- write-through stores, then a ticket on the tile) and may continue into the next tile from k = 0 (its HEAD part):
-// the workgroup holding k = 0 owns the tile, waits for the tile's tickets, adds the slabs of the following workgroups in
-// order and runs the normal epilogue.  Tails are computed first and heads last in every range, so an owner practically never
-// waits.  Hand-off as in the split-K reducer above (sc1 stores / relaxed agent ticket / sc1 loads, no fences).
-// =====================================================================================
-template <bool TA, bool TB>
-__device__ __forceinline__ void p8_segment(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, int K,
-                                           int m0, int n0, int M, int N, int t_begin, int nt, unsigned char* smem_raw, int wave,
-                                           int wr, int wc, int lane, f32x4 (&acc)[8][4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef DmaOperand<TA, 128, 512, 64> OpA;
-    typedef DmaOperand<TB, 128, 512, 64> OpB;
-    constexpr int HALF = 16384;
-    OpA opa; OpB opb;
-    opa.init(A, lda, m0, M, K, wave, lane);
-    opb.init(B, ldb, n0, N, K, wave, lane);
-    const int a_half = TA ? 256 : 128 * lda * 2;
-    const int b_half = TB ? 256 : 128 * ldb * 2;
-    f32x4 accb[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
-    opa.issue(t_begin, smem_raw, wave, 0);
-    opa.issue(t_begin, smem_raw + HALF, wave, a_half);
-    opb.issue(t_begin, smem_raw + 2 * HALF, wave, 0);
-    opb.issue(t_begin, smem_raw + 3 * HALF, wave, b_half);
-    if (nt > 1) {
-        opb.issue(t_begin + 1, smem_raw + 65536 + 2 * HALF, wave, 0);
-        opb.issue(t_begin + 1, smem_raw + 65536 + 3 * HALF, wave, b_half);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OpB::NLOAD) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) {
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int t = 0; t < nt; t += 2) {
-        P8Tile<TA, TB, false, 0>::run(smem_raw, opa, opb, a_half, b_half, t, nt, t_begin, wave, wr, wc, lane, acc, accb, false);
-        if (t + 1 < nt)
-            P8Tile<TA, TB, false, 1>::run(smem_raw, opa, opb, a_half, b_half, t + 1, nt, t_begin, wave, wr, wc, lane, acc, accb, false);
-    }
-    if (wr == 0) {
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();            // every wave is done with the operand tiles
-#endif
+// packed copy of one B operand (ilvlm_gemm_pack_b): one thread per 16-byte chunk
+__global__ __launch_bounds__(256) void pack_b_kernel(const bf16* __restrict__ B, int ldb, int trans, int N, int K, bf16* __restrict__ out) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (long)N * K / 8) return;
+    const int l = (int)(c & 63);
+    const long blk = c >> 6;
+    const int kblocks = K >> 5;
+    const int n = (int)(blk / kblocks) * 16 + (l & 15), k0 = (int)(blk % kblocks) * 32 + 8 * (l >> 4);
+    bf16x8 v;
+    if (!trans) v = *(const bf16x8*)(B + (long)n * ldb + k0);
+    else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = B[(long)(k0 + j) * ldb + n];
+    *(bf16x8*)(out + c * 8) = v;
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p8sk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                                int ldb, int K, int tiles_m, int tiles_n, EpiArgs ep) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int nt = K / 64, P = gridDim.x, w = blockIdx.x;
-    const long I = (long)tiles_m * tiles_n * nt;
-    long it0 = I * w / P;
-    const long it1 = I * (w + 1) / P;
-    float alpha = ep.e.alpha;
-    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    constexpr int SLAB = 256 * 256 * 4;
-    __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(ep.e.splitk_ws, 0, P * SLAB, 0x00020000);
-    f32x4 acc[8][4];
-    while (it0 < it1) {
-        const int tile = (int)(it0 / nt), k0 = (int)(it0 % nt);
-        const int k1 = (int)((it1 - it0) < (long)(nt - k0) ? k0 + (it1 - it0) : nt);
-        const int tn = tile % tiles_n, tm = tile / tiles_n;
-        const int m0 = tm * 256, n0 = tn * 256;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-        p8_segment<TA, TB>(A, lda, B, ldb, K, m0, n0, ep.M, ep.N, k0, k1 - k0, smem_raw, wave, wr, wc, lane, acc);
-        if (k0 != 0) {
-            // contributor: this workgroup's one slab (slot = its index), then a ticket on the tile
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    union { f32x4 f; u32x4 u; } x;
-                    x.f = acc[i][j];
-                    __builtin_amdgcn_raw_buffer_store_b128(x.u, ws, w * SLAB + ((i * 4 + j) * 512 + tid) * 16, 0, 16);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(ep.e.splitk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (k1 != nt) {
-                // owner of a tile other workgroups finish: they are w + 1 .. the workgroup holding the tile's last iteration
-                const long last_it = (long)(tile + 1) * nt - 1;
-                int wl = (int)(last_it * P / I);
-                while (I * (wl + 1) / P <= last_it) ++wl;
-                while (I * wl / P > last_it) --wl;
-                const int ncontrib = wl - w;
-                if (tid == 0) {
-                    while (__hip_atomic_load(ep.e.splitk_cnt + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ncontrib)
-                        __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(ep.e.splitk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int c = 1; c <= ncontrib; ++c) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            union { f32x4 f; u32x4 u; } x;
-                            x.u = __builtin_amdgcn_raw_buffer_load_b128(ws, (w + c) * SLAB + ((i * 4 + j) * 512 + tid) * 16, 0, 16);
-                            acc[i][j] += x.f;
-                        }
-                }
-            }
-            epilogue_tile<8, 4>(ep, acc, m0 + wr * 128, n0 + wc * 64, lane, alpha, smem_raw + wave * 8192);
-            __syncthreads();    // the transpose slices are the operand buffers of the next segment
-        }
-        it0 += k1 - k0;
+// packed copies of every GEMM weight of a bf16 arena (ilvlm_pack_weights): one workgroup per 64 x 64 tile of a weight
+// W [rows, cols]; fwd = image of Bop[n][k] = W[n][k], bwd = image of Bop[n'][k'] = W[k'][n'] (the input gradient dY W)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const bf16* __restrict__ S, bf16* __restrict__ fwd, bf16* __restrict__ bwd,
+                                                           const int* __restrict__ table) {
+    __shared__ __attribute__((aligned(16))) bf16 tile[64][64 + 8];
+    const int* e = table + (long)blockIdx.x * 5;
+    const long off = (long)e[0] * 64;
+    const int rows = e[1], cols = e[2], r0 = e[3], c0 = e[4];
+    const int t = threadIdx.x;
+    {
+        const int r = t >> 2, cq = (t & 3) * 16;
+        const bf16* src = S + off + (long)(r0 + r) * cols + c0 + cq;
+        *(bf16x8*)&tile[r][cq] = *(const bf16x8*)src;
+        *(bf16x8*)&tile[r][cq + 8] = *(const bf16x8*)(src + 8);
     }
-#endif
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = t + 256 * h, blk = c >> 6, l = c & 63, hi = blk >> 1, lo = blk & 1;
+        // forward image: column tile hi (W rows), k-step lo (W columns)
+        {
+            const int n = 16 * hi + (l & 15), k = 32 * lo + 8 * (l >> 4);
+            const long b = (long)((r0 >> 4) + hi) * (cols >> 5) + (c0 >> 5) + lo;
+            *(bf16x8*)(fwd + off + b * 512 + l * 8) = *(const bf16x8*)&tile[n][k];
+        }
+        // backward image: column tile hi (W columns), k-step lo (W rows)
+        {
+            const int n = 16 * hi + (l & 15), k = 32 * lo + 8 * (l >> 4);
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[k + j][n];
+            const long b = (long)((c0 >> 4) + hi) * (rows >> 5) + (r0 >> 5) + lo;
+            *(bf16x8*)(bwd + off + b * 512 + l * 8) = v;
+        }
+    }
 }
 
 // =====================================================================================
@@ -1585,45 +1418,14 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB, int FP8 = 0>
-int launch_persist(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_persist_kernel<TA, TB, FP8>;
-    constexpr int bytes = 32768 + 4 * 4096;
-    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
-    static const int wgs = getenv("ILVLM_PERSIST_WGS") ? atoi(getenv("ILVLM_PERSIST_WGS")) : 768;     // 3 per CU
-    int grid = tm * tn < wgs ? (tm * tn + 7) / 8 * 8 : wgs;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, s, A, lda, B, ldb, K, tm, tn, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_persist");
-    return ILVLM_OK;
-}
-
-template <bool TA, bool TB, bool ACC>
-int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_p8_kernel<TA, TB, ACC>;
-    constexpr int bytes = 131072;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
-    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_p8: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
-    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_p8");
-    return ILVLM_OK;
-}
-
-constexpr int ILVLM_SK_GRID = 256;     // one workgroup per CU of an MI355X
-
-template <bool TA, bool TB>
-int launch_p8sk(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_p8sk_kernel<TA, TB>;
-    constexpr int bytes = 131072;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
-    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_p8sk: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
-    hipLaunchKernelGGL(kern, dim3(ILVLM_SK_GRID), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_p8sk");
+template <int WN>
+int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_pk_kernel<WN>;
+    constexpr int ring = 2 * 128 * 64 * 2, epi = WN * 8192;
+    constexpr int bytes = ring > epi ? ring : epi;
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, ep);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
     return ILVLM_OK;
 }
 
@@ -1640,10 +1442,14 @@ int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, 
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-// 0 = register-staged general kernel only; 5 = direct-to-LDS 128x128 single stage (default: fastest inside the step);
-// 6 = 64x128 tiles where the A operand is K-contiguous; 7 = direct-to-LDS 256x128, 8 waves, 3-stage ring.  (Round-1 exploration also
-// measured global_load_lds addressing, double buffering, 256x256 and BK=32 variants -- all slower; see DESIGN.md.)
-std::atomic<int> g_gemm_variant{5};
+// bf16 kernel selection (a tuning / test hook, ilvlm_gemm_set_variant):
+//   15 (default) = the streaming kernel (weights pre-packed in fragment order, gemm_bf16_pk_kernel) wherever the caller
+//                  offers a packed copy of B, the direct-to-LDS 128x128 kernel everywhere else;
+//    5           = always the direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
+//    0           = the register-staged general kernel only.
+// The tilings and pipelines that rounds 1 and 2 measured and lost with (64x128, 256x128 3-stage, 256x256 phased, stream-K,
+// persistent, 2-/3-deep rings, 128-deep K-tiles) live in the git history; DESIGN.md section 6 has their numbers.
+std::atomic<int> g_gemm_variant{15};
 
 }  // namespace
 
@@ -1728,11 +1534,6 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             slab_setup(128);
             return launch_dma<true, true, false, 128, 128, 2, 2, 1, 64, 3>((const bf16*)A, lda, (const bf16*)B, ldb, K, M, N, split_k, ep, s);
         }
-        if (g_gemm_variant.load(std::memory_order_relaxed) == 13) {     // persistent form (A/B)
-            if (compute_dtype == ILVLM_FP8)
-                return launch_persist<false, false, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N, ep, s);
-            return launch_persist<false, false, 2>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N, ep, s);
-        }
         if (compute_dtype == ILVLM_FP8)
             return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N,
                                                                            1, ep, s);
@@ -1757,67 +1558,31 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // descriptors' extent and read as zeros, so any K works -- the packed text rows need exactly that.
         const bool fast = (variant != 0 || epi->pool_out) && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
-        // 8 = 256x256 phased kernel (one workgroup per CU): the tall GEMMs of the towers
-        // A/B rule (ILVLM_GEMM_AUTO8=<K threshold>, off by default): send the store-type GEMMs with a narrow output and a deep
-        // reduction (N <= 768, K >= threshold: down-projection forward, up-projection / in-projection input gradients) to the
-        // 256x256 phased kernel.  They have only 90...150 tiles of 256x256, so it occupies that many CUs with one workgroup
-        // each and leaves the rest to the other streams: +1.1 %, +0.8 % and +0.0 % of the step in three same-box runs.
-        static const int auto8 = getenv("ILVLM_GEMM_AUTO8") ? atoi(getenv("ILVLM_GEMM_AUTO8")) : 0;
-        const bool pick8 = auto8 > 0 && variant == 5 && swap && N <= 768 && K >= auto8 && M >= 4096 && !epi->pool_out;
-        // variant 14 (A/B): the stream-K form of that kernel; needs the caller's slab workspace (epilogue splitk_* fields:
-        // 64 MiB of slabs, zeroed ticket counters) and at least two K-tiles of work per workgroup
-        if (fast && variant == 14 && swap && !trans_a && K % 64 == 0 && !epi->pool_out && slab_ws && epi->splitk_cnt &&
-            epi->splitk_ws_bytes >= (long)ILVLM_SK_GRID * 256 * 256 * 4 && epi->splitk_cnt_len >= ceil_div(M, 256) * ceil_div(N, 256) &&
-            (long)ceil_div(M, 256) * ceil_div(N, 256) * (K / 64) >= 2L * ILVLM_SK_GRID) {
-            ep.e.splitk_ws = slab_ws;
-            if (trans_b) return launch_p8sk<false, true>(a, lda, b, ldb, K, M, N, ep, s);
-            return launch_p8sk<false, false>(a, lda, b, ldb, K, M, N, ep, s);
-        }
-        if (fast && (variant == 8 || pick8) && M >= 256 && N >= 256) {
-#define ILVLM_P8(TA, TB)                                                                                 \
-    return swap ? launch_p8<TA, TB, false>(a, lda, b, ldb, K, M, N, split_k, ep, s)                      \
-                : launch_p8<TA, TB, true>(a, lda, b, ldb, K, M, N, split_k, ep, s)
-            if (!trans_a && !trans_b) { ILVLM_P8(false, false); }
-            if (!trans_a && trans_b) { ILVLM_P8(false, true); }
-            if (trans_a && !trans_b) { ILVLM_P8(true, false); }
-            ILVLM_P8(true, true);
-#undef ILVLM_P8
+        // streaming kernel: the caller offers B in fragment order (weights); A must be K-contiguous, whole K-tiles
+        if (variant == 15 && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
+            (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
+            static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 2;
+            const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
+            const int tn_pk = ceil_div(N, 64 * wn);
+            ep.tile_group = (tile_group_env > 0 && K <= tile_kmax_env && tn_pk > tile_group_env) ? tile_group_env : 0;
+            if (wn == 4) return launch_pk<4>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
+            return launch_pk<2>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
         }
         if (fast) {
-            // 5 (default) = 128x128 / 4 waves / 1 stage (4 workgroups per CU); 7 = 256x128 / 8 waves / 3-stage ring;
-            // 6 = 64x128 tiles (K-contiguous A only).  6 is 3..27 % faster in isolation on launches that leave most
-            // of the chip's 1024 workgroup slots empty (N = 512 / 768 outputs, the packed text rows;
-            // benchmarks/gemm_bench.py) but 6.5 % SLOWER inside the two-stream step, where the other tower's kernels
-            // fill those slots and the doubled weight re-reads cost more -- so it is never selected automatically.
-            if (swap && variant == 13 && !trans_a && K % BK == 0) {     // persistent 128x128 (A/B)
-                if (trans_b) return launch_persist<false, true>(a, lda, b, ldb, K, M, N, ep, s);
-                return launch_persist<false, false>(a, lda, b, ldb, K, M, N, ep, s);
-            }
-            if (!swap && (variant == 5 || variant >= 10)) slab_setup(variant == 12 ? 128 : 64);
-            // 10 / 11: the weight-gradient form with a 2- / 3-deep operand ring (64 / 96 KB of LDS, 2 / 1 workgroups per CU)
-            if (!swap && trans_a && trans_b && variant == 10)
+            // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU
+            if (!swap) slab_setup(64);
+            // weight gradients (both operands K-strided, accumulate): two-stage operand ring -- K-tile t+1 is in flight while
+            // t is multiplied (64 KiB of LDS, two workgroups per CU).  Round 2 measured this form 3 % SLOWER; that build
+            // was not pipelined at all (compiler-inserted vmcnt(0) behind the DMA builtin, see DmaOperand::issue).
+            static const int wgrad_stages = getenv("ILVLM_WGRAD_STAGES") ? atoi(getenv("ILVLM_WGRAD_STAGES")) : 2;
+            if (!swap && trans_a && trans_b && wgrad_stages == 2 && variant != 5)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
-            if (!swap && trans_a && trans_b && variant == 11)
-                return launch_dma<true, true, false, 128, 128, 2, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);
-            if (!swap && trans_a && trans_b && variant == 12) {      // K-tiles of 128: 64 KB per workgroup and wait
-                int nt128 = ceil_div(K, 128);
-                return launch_dma<true, true, false, 128, 128, 2, 2, 1, 128>(a, lda, b, ldb, K, M, N, split_k > nt128 ? nt128 : split_k, ep, s);
-            }
 #define ILVLM_DMA(TA, TB)                                                                                            \
-    do {                                                                                                             \
-        if (variant == 7)                                                                                            \
-            return swap ? launch_dma<TA, TB, true, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s)       \
-                        : launch_dma<TA, TB, false, 256, 128, 4, 2, 3>(a, lda, b, ldb, K, M, N, split_k, ep, s);     \
-        if (swap && !trans_a && variant == 6)                                                                        \
-            return launch_dma<TA, TB, true, 64, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);              \
-        if (swap && variant == 9)                                                                                    \
-            return launch_dma<TA, TB, true, 256, 128, 4, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);             \
-        return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)           \
-                    : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);         \
-    } while (0)
-            if (!trans_a && !trans_b) ILVLM_DMA(false, false);
-            if (!trans_a && trans_b) ILVLM_DMA(false, true);
-            if (trans_a && !trans_b) ILVLM_DMA(true, false);
+    return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)               \
+                : launch_dma<TA, TB, false, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)
+            if (!trans_a && !trans_b) { ILVLM_DMA(false, false); }
+            if (!trans_a && trans_b) { ILVLM_DMA(false, true); }
+            if (trans_a && !trans_b) { ILVLM_DMA(true, false); }
             ILVLM_DMA(true, true);
 #undef ILVLM_DMA
         }
@@ -1847,8 +1612,27 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || (variant >= 5 && variant <= 14), "gemm_set_variant: 0 or 5 .. 14");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 15, "gemm_set_variant: 0, 5 or 15");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int ldb, void* packed, void* stream) {
+    ILVLM_REQUIRE(B && packed && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "gemm_pack_b: N %% 16 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    ILVLM_REQUIRE(ldb >= (trans_b ? N : K) && ldb % 8 == 0 && aligned(B, 16) && aligned(packed, 16), "gemm_pack_b: alignment / ldb");
+    const long chunks = (long)N * K / 8;
+    hipLaunchKernelGGL(pack_b_kernel, dim3((int)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)B, ldb,
+                       trans_b, N, K, (bf16*)packed);
+    ILVLM_LAUNCH_CHECK("gemm_pack_b");
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, const int32_t* table, int n_tiles, void* stream) {
+    ILVLM_REQUIRE(arena_bf16 && fwd && bwd && table && n_tiles > 0, "pack_weights: bad arguments");
+    ILVLM_REQUIRE(aligned(arena_bf16, 16) && aligned(fwd, 16) && aligned(bwd, 16), "pack_weights: 16-byte aligned arenas");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)arena_bf16, (bf16*)fwd,
+                       (bf16*)bwd, table);
+    ILVLM_LAUNCH_CHECK("pack_weights");
     return ILVLM_OK;
 }
 

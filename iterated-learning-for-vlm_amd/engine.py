@@ -213,6 +213,40 @@ class Fp8State:
         return ops.fp8_quantize(x, torch.empty(x.shape, dtype=torch.uint8, device=x.device), sc, am, e5m2)
 
 
+class PackedWeights:
+    """Fragment-order copies of the GEMM weights of the residual attention blocks (bf16 mode): the forward image (B operand of
+    x W^T) and the input-gradient image (B operand of dY W) of every [out, in] weight, at the weight's own arena offset in
+    two arena-shaped bf16 buffers.  One launch (ilvlm_pack_weights) re-packs all of them from the bf16 shadow; the eight
+    store-type GEMMs of a block then run the streaming kernel (include/ilvlm_hip.h, ilvlm_gemm_epilogue.b_packed), which
+    reads them in whole 1 KiB wave loads straight into MFMA operand registers."""
+    WNAME = Fp8State.WNAME
+
+    def __init__(self, arena, block_prefixes):
+        dev = arena.P.device
+        self.arena = arena
+        table = []
+        for pre in block_prefixes:
+            for k, wn in self.WNAME.items():
+                name = pre + wn
+                r, c = arena.views[name].shape
+                if r % 64 or c % 64 or arena.offsets[name] % 64:
+                    raise RuntimeError("packed weights: %s [%d,%d] is not a multiple of 64 x 64" % (name, r, c))
+                for r0 in range(0, r, 64):
+                    for c0 in range(0, c, 64):
+                        table.append((arena.offsets[name] // 64, r, c, r0, c0))
+        self.table = torch.tensor(table, dtype=torch.int32).to(dev)
+        self.fwd = torch.zeros(arena.total, dtype=torch.bfloat16, device=dev)
+        self.bwd = torch.zeros(arena.total, dtype=torch.bfloat16, device=dev)
+
+    def refresh(self):
+        ops.pack_weights(self.arena.S, self.fwd, self.bwd, self.table)
+
+    def view(self, name, backward=False):
+        o = self.arena.offsets[name]
+        n = self.arena.views[name].numel()
+        return (self.bwd if backward else self.fwd)[o:o + n]
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -231,6 +265,8 @@ class Engine:
         # fp8 operands with per-tensor delayed scaling (Fp8State)
         self.T = torch.float32 if self.precision == "fp32" else torch.bfloat16
         self.fp8 = None
+        self.packed = None        # PackedWeights (bf16 mode): fragment-order weight copies for the streaming GEMM kernel
+        self.use_packed = os.environ.get("ILVLM_PACKED_WEIGHTS", "1") == "1"
         self.arena = None
         self._side = None
         self.concurrent_towers = True     # False: everything on the current stream (per-kernel timing, debugging)
@@ -289,12 +325,18 @@ class Engine:
         self.Wf = a.views                                     # fp32 masters
         self.Wc = a.views if self.precision == "fp32" else a.sviews   # GEMM operands
         self.Gr = a.gviews
+        pres = ["visual.transformer.resblocks.%d." % i for i in range(self.cfg["v_layers"])] + \
+               ["encode_text.transformer.resblocks.%d." % i for i in range(self.cfg["t_layers"])]
         if self.precision == "fp8":
             if self.fp8 is None:
-                pres = ["visual.transformer.resblocks.%d." % i for i in range(self.cfg["v_layers"])] + \
-                       ["encode_text.transformer.resblocks.%d." % i for i in range(self.cfg["t_layers"])]
                 self.fp8 = Fp8State(a, pres)
             self.fp8.begin_step(bool(training))
+        if self.precision == "bf16" and self.use_packed:
+            # the streaming GEMM kernel reads the block weights in fragment order: re-pack from the (now current) shadow
+            if self.packed is None:
+                self.packed = PackedWeights(a, pres)
+                self._blk = {}
+            self.packed.refresh()
         req = {n: p.requires_grad for n, p in a.named}
         if req != getattr(self, "req", None):
             self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots
@@ -357,6 +399,10 @@ class Engine:
                 params = {k: (self.Wc if k in ("in_w", "out_w", "fc_w", "proj_w") else self.Wf)[pre + n] for k, n in names.items()}
                 grads = {"g_" + k: (self.Gr[pre + n] if self.req[pre + n] else None) for k, n in names.items()}
                 d = ops.block_desc(E, H, causal, self.T, params, grads)
+                if self.packed is not None:
+                    for k in PackedWeights.WNAME:
+                        setattr(d, k + "p", self.packed.view(pre + names[k]).data_ptr())
+                        setattr(d, k + "pt", self.packed.view(pre + names[k], backward=True).data_ptr())
                 if self.fp8 is not None:
                     f8 = self.fp8
                     base = f8.slots[pre + "h1"]
@@ -370,6 +416,12 @@ class Engine:
         if d and self.fp8 is not None:
             d.fp8 = (3 if self.fp8_wgrad else 2) if self.fp8.active else 1
         return d or None
+
+    def _packed(self, name, backward=False):
+        """fragment-order copy of a block weight (None: not a packed weight / packing off)"""
+        if self.packed is None or not name.endswith(tuple(PackedWeights.WNAME.values())) or ".resblocks." not in name:
+            return None
+        return self.packed.view(name, backward)
 
     def _mat(self, name):
         w = self.Wc[name]
@@ -418,7 +470,7 @@ class Engine:
             ops.gemm_fp8(dy8, self.fp8.w8(pre, kw_, transposed=True), dx, self.fp8.s(pre + kg)[1], self.fp8.s(pre + kw_)[1],
                          a_e5m2=True, aux=dx_aux, act=dx_act)
         else:
-            ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act)
+            ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act, b_packed=self._packed(wname, backward=True))
         return dx
 
     # ------------------------------------------------------------------ transformer block
@@ -441,7 +493,7 @@ class Engine:
             if x8 is not None:
                 ops.gemm_fp8(x8, f8.w8(pre, key_w), out, f8.s(pre + key_a)[1], f8.s(pre + key_w)[1], **kw)
             else:
-                ops.gemm(x, self._mat(pre + wname), out, **kw)
+                ops.gemm(x, self._mat(pre + wname), out, b_packed=self._packed(pre + wname), **kw)
             return x8
 
         h1 = _empty((M, E), T, x_in); mean1 = _empty((M,), torch.float32, x_in); rstd1 = torch.empty_like(mean1)

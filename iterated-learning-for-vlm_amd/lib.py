@@ -20,7 +20,8 @@ class GemmEpilogue(C.Structure):
                 ("out_group", i32), ("out_skip", i32), ("a_rowsum", vp),
                 ("pool_out", vp), ("pool_seq", vp), ("pool_offs", vp), ("pool_group", i32), ("alpha_ptr2", vp),
                 ("out8", vp), ("out8_scale", vp), ("out8_amax", vp), ("out8_fmt", i32),
-                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32),
+                ("b_packed", vp)]
 
 
 class Block(C.Structure):
@@ -31,7 +32,8 @@ class Block(C.Structure):
                 [("E", i32), ("H", i32), ("causal", i32), ("dtype", i32)] +
                 [(n, vp) for n in ("in_w8", "out_w8", "fc_w8", "proj_w8", "in_w8t", "out_w8t", "fc_w8t", "proj_w8t", "f8_scale",
                                    "f8_inv", "f8_amax")] + [("fp8", i32)] +
-                [("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)])
+                [("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)] +
+                [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")])
 
 
 class AdamWHyper(C.Structure):
@@ -43,6 +45,8 @@ class AdamWHyper(C.Structure):
 SIGNATURES = {
     "ilvlm_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(GemmEpilogue), i32, vp],
     "ilvlm_gemm_set_variant": [i32],
+    "ilvlm_gemm_pack_b": [i32, i32, i32, vp, i32, vp, vp],
+    "ilvlm_pack_weights": [vp, vp, vp, vp, i32, vp],
     "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
     "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "ilvlm_layernorm_fwd_q8": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp, vp],

@@ -128,9 +128,11 @@ def set_gemm_profiler(p):
 
 def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, residual=None, aux=None, act=0,
          alpha=1.0, alpha_ptr=None, accumulate=False, out_group=0, out_skip=0, split_k=1, M=None, N=None, K=None,
-         a_rowsum=None, slab=None):
+         a_rowsum=None, slab=None, b_packed=None):
     """out[m,n] = epilogue(sum_k A(m,k) B(n,k)); see ilvlm_gemm.  a, b: 2-D bf16 or fp32 (same dtype);
-    out: 2-D.  With out_group > 0, `out` is the token-stream tensor the rows are mapped into."""
+    out: 2-D.  With out_group > 0, `out` is the token-stream tensor the rows are mapped into.
+    b_packed: the B operand in MFMA-fragment order (gemm_pack_b / pack_weights), n * k bf16 elements: the streaming
+    kernel takes store-type bf16 GEMMs with it (bit-identical results)."""
     if a.dtype != b.dtype:
         raise RuntimeError("gemm: operand dtypes differ: %s %s" % (a.dtype, b.dtype))
     _chk(a, "gemm.a"); _chk(b, "gemm.b"); _chk(out, "gemm.out")
@@ -165,6 +167,11 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
     if slab is not None:          # (workspace uint8, counters int32): slab split-K instead of atomics (ilvlm_gemm_epilogue)
         epi.splitk_ws, epi.splitk_ws_bytes = slab[0].data_ptr(), slab[0].numel()
         epi.splitk_cnt, epi.splitk_cnt_len = slab[1].data_ptr(), slab[1].numel()
+    if b_packed is not None:
+        _chk(b_packed, "gemm.b_packed", torch.bfloat16)
+        if b_packed.numel() != n * k or a.dtype != torch.bfloat16:
+            raise RuntimeError("gemm: b_packed must hold n * k = %d bf16 elements (bf16 GEMMs only), got %d" % (n * k, b_packed.numel()))
+        epi.b_packed = b_packed.data_ptr()
     prof = _gemm_profiler if (_gemm_profiler is not None and a.dtype == torch.bfloat16) else None
     if _gemm_profiler is not None and prof is None:
         _gemm_profiler.f32_flops += 2.0 * m * n * k
@@ -253,6 +260,28 @@ def fp8_quantize(src, dst, scale, amax, e5m2=False):
     L.check(L.load().ilvlm_fp8_quantize(src.data_ptr(), dt(src), _p(dst), src.numel(), _p(scale), _p(amax), int(bool(e5m2)),
                                         _stream()), "fp8_quantize")
     return dst
+
+
+def gemm_pack_b(b, trans_b=False, out=None):
+    """B operand (2-D bf16; [N,K], or [K,N] with trans_b) in MFMA-fragment order for gemm(b_packed=...)"""
+    _chk(b, "gemm_pack_b.b", torch.bfloat16)
+    n, k = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if out is None:
+        out = torch.empty(n * k, dtype=torch.bfloat16, device=b.device)
+    _chk(out, "gemm_pack_b.out", torch.bfloat16, (n * k,))
+    L.check(L.load().ilvlm_gemm_pack_b(int(trans_b), n, k, b.data_ptr(), b.stride(0), out.data_ptr(), _stream()), "gemm_pack_b")
+    return out
+
+
+def pack_weights(arena_bf16, fwd, bwd, table):
+    """fragment-order copies (forward / input-gradient images) of every GEMM weight listed in `table` (int32 [n, 5])"""
+    for t, nm in ((arena_bf16, "arena"), (fwd, "fwd"), (bwd, "bwd")):
+        _chk(t, "pack_weights." + nm, torch.bfloat16)
+    _chk(table, "pack_weights.table", torch.int32)
+    if fwd.numel() != arena_bf16.numel() or bwd.numel() != arena_bf16.numel() or table.dim() != 2 or table.shape[1] != 5:
+        raise RuntimeError("pack_weights: arena-shaped outputs and an [n, 5] table are required")
+    L.check(L.load().ilvlm_pack_weights(arena_bf16.data_ptr(), fwd.data_ptr(), bwd.data_ptr(), table.data_ptr(), table.shape[0],
+                                        _stream()), "pack_weights")
 
 
 def gemm_set_variant(v):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), "libilvlm_hip.so does not export %s" % n
     # and the ctypes table binds every one of them (except the two argument-less queries)
     assert set(names) - {"ilvlm_version", "ilvlm_last_error"} == set(lib.SIGNATURES)
-    assert handle.ilvlm_version() == 200
+    assert handle.ilvlm_version() == 300
 
 
 def test_ctypes_table_has_the_headers_argument_counts():

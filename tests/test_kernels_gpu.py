@@ -52,13 +52,13 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (24, 384, 128), (328, 64, 40), (1
 GEMM_SHAPES_F32_ODD = [(3, 3, 64), (5, 15, 33), (67, 3, 130), (3, 130, 5)]
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8, 13])
+@pytest.mark.parametrize("variant", [5, 15])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 392, 256), (136, 2304, 768), (8, 8, 128), (512, 256, 64),
                                    (776, 520, 192)])
 def test_gemm_direct_to_lds_variants(variant, ta, tb, M, N, K):
-    """the direct-to-LDS kernels (128x128 single stage, 256x128 three-stage ring), incl. ragged M/N tiles, split-K and
-    the fused bias-gradient row sum"""
+    """the direct-to-LDS 128x128 kernel under both selector settings (5 = always; 15 = default, which only differs where a
+    packed B operand is offered), incl. ragged M/N tiles, split-K and the fused bias-gradient row sum"""
     ops = _ops()
     a, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2).to(torch.bfloat16)
     want = a.float() @ b.float().t()
@@ -80,7 +80,7 @@ def test_gemm_direct_to_lds_variants(variant, ta, tb, M, N, K):
             if M % 8 == 0:
                 assert rel(rs, 1 + a.float().sum(1)) < 2e-5
     finally:
-        ops.gemm_set_variant(5)
+        ops.gemm_set_variant(15)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -611,30 +611,121 @@ def test_weight_gradient_gemm_with_ragged_reduction(K):
     assert rel(bias, a.float().sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8, 13])
+@pytest.mark.parametrize("variant", [5, 15])
 @pytest.mark.parametrize("M,N,K,tb", [(19712, 2048, 512, 0), (12800, 3072, 768, 0), (12800, 768, 3072, 1), (11319, 1536, 512, 0)])
 def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, tb):
     """Chip-filling launches of the step's shapes, repeated: every launch must reproduce the first bit for bit (no atomics in
     these kernels) and match an fp32 reference.  Guards the LDS race fixed at ILVLM_WG_BARRIER (csrc/gemm.hip): fragment reads
     still queued at the end-of-K-tile barrier were overtaken by the next tile's DMA in about one launch out of ten -- only at
-    sizes where four workgroups per CU keep the LDS pipeline busy, never at unit-test sizes."""
+    sizes where four workgroups per CU keep the LDS pipeline busy, never at unit-test sizes.  Variant 15 runs the streaming
+    kernel (packed B operand, hand-placed waits around inline-asm loads): same guard for its two-stage ring, and its result
+    must equal the direct-to-LDS kernel's bit for bit (same MFMA sequence per output element)."""
     ops = _ops()
     a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
     w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
     ref = a.float() @ (w.float() if tb else w.float().t())
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant == 15 else None
     try:
+        ops.gemm_set_variant(5)
+        base = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        ops.gemm(a, w, base, trans_b=bool(tb))
         ops.gemm_set_variant(variant)
         first = None
         for it in range(25):
             out = torch.empty(M, N, device="cuda", dtype=torch.float32)
-            ops.gemm(a, w, out, trans_b=bool(tb))
+            ops.gemm(a, w, out, trans_b=bool(tb), b_packed=wp)
             if first is None:
                 first = out
                 assert float((out - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+                assert torch.equal(out, base), "streaming kernel differs from the direct-to-LDS kernel"
             else:
                 assert torch.equal(out, first), "launch %d differs from launch 0" % it
     finally:
+        ops.gemm_set_variant(15)
+
+
+def _unpack_b(packed, n, k):
+    """inverse of the fragment order of ilvlm_gemm_pack_b (include/ilvlm_hip.h): [n, k] from the packed image"""
+    p = packed.view(n // 16, k // 32, 4, 16, 8)           # block (n/16, k/32), lane = 16 * (l >> 4) + (l & 15), 8 elements
+    return p.permute(0, 3, 1, 2, 4).reshape(n, k)
+
+
+@pytest.mark.parametrize("N,K", [(16, 32), (64, 64), (768, 3072), (2304, 768), (80, 96)])
+def test_gemm_pack_b_layout(N, K):
+    """the packed B operand is exactly the documented permutation of B (both storage orders)"""
+    ops = _ops()
+    b = rnd(N, K, seed=5).to(torch.bfloat16)
+    for tb in (False, True):
+        src = dev(b.t()) if tb else dev(b)
+        packed = ops.gemm_pack_b(src, trans_b=tb).cpu()
+        assert torch.equal(_unpack_b(packed, N, K), b), "trans_b=%s" % tb
+
+
+def test_pack_weights_table_equals_single_matrix_packs():
+    """ilvlm_pack_weights (all GEMM weights of an arena in one launch) = ilvlm_gemm_pack_b per weight, both images"""
+    ops = _ops()
+    shapes = [(192, 64), (64, 256), (128, 128)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += r * c + 64                     # gaps between the weights (other parameters live there)
+    arena = rnd(total, seed=9).to(torch.bfloat16).cuda()
+    table = [(o // 64, r, c, r0, c0) for o, (r, c) in zip(offs, shapes) for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+    fwd = torch.zeros(total, dtype=torch.bfloat16, device="cuda")
+    bwd = torch.zeros(total, dtype=torch.bfloat16, device="cuda")
+    ops.pack_weights(arena, fwd, bwd, torch.tensor(table, dtype=torch.int32).cuda())
+    for o, (r, c) in zip(offs, shapes):
+        w = arena[o:o + r * c].view(r, c)
+        assert torch.equal(fwd[o:o + r * c], ops.gemm_pack_b(w))                      # Bop[n][k] = W[n][k]
+        assert torch.equal(bwd[o:o + r * c], ops.gemm_pack_b(w, trans_b=True))        # Bop[n'][k'] = W[k'][n']
+        assert float(fwd[o + r * c:o + r * c + 64].abs().sum()) == 0.0               # gaps untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 400, 256), (136, 2304, 768), (8, 16, 128), (512, 256, 192),
+                                   (776, 528, 320), (300, 64, 64), (129, 144, 448)])
+@pytest.mark.parametrize("tb", [0, 1])
+def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, monkeypatch):
+    """gemm_bf16_pk_kernel (A through a two-stage LDS ring, B from the packed copy straight into registers): odd and even
+    K-tile counts, ragged row tiles, column counts that are not multiples of the 128-column tile, every store epilogue --
+    against an fp32 reference AND bit for bit against the direct-to-LDS kernel"""
+    ops = _ops()
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb))
+    ref = a.float() @ (w.float() if tb else w.float().t())
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    pre = rnd(M, N, seed=6).to(torch.bfloat16).cuda()
+
+    def run(packed, **kw):
+        outs = []
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, out, trans_b=bool(tb), b_packed=packed, **kw)
+        outs.append(out)
+        outb = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outb, trans_b=bool(tb), b_packed=packed, bias=bias)
+        outs.append(outb)
+        outr = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, outr, trans_b=bool(tb), b_packed=packed, bias=bias, residual=res)
+        outs.append(outr)
+        aux = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        outg = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outg, trans_b=bool(tb), b_packed=packed, bias=bias, aux=aux, act=1)          # QuickGELU forward
+        outs += [outg, aux]
+        outd = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outd, trans_b=bool(tb), b_packed=packed, aux=pre, act=3)                     # QuickGELU backward
+        outs.append(outd)
+        return outs
+
+    got = run(wp)
+    try:
         ops.gemm_set_variant(5)
+        base = run(None)
+    finally:
+        ops.gemm_set_variant(15)
+    assert rel(got[0], ref) < 2e-5
+    assert rel(got[2], ref + bias + res) < 2e-5
+    for i, (g, b) in enumerate(zip(got, base)):
+        assert torch.equal(g, b), "epilogue case %d differs from the direct-to-LDS kernel" % i
 
 
 @pytest.mark.parametrize("M,N,K,split", [(2048, 512, 19712, 6), (3072, 768, 12800, 3), (512, 512, 11319, 16)])
@@ -652,39 +743,6 @@ def test_weight_gradient_gemm_at_full_size(M, N, K, split):
         ops.gemm(a, b, out, trans_a=True, trans_b=True, accumulate=True, split_k=split, a_rowsum=rs)
         assert float((out - ref).abs().max()) < 1e-3 * scale, "launch %d" % it
         assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
-
-
-@pytest.mark.parametrize("M,N,K,tb", [(12800, 768, 3072, 0), (12800, 768, 2304, 1), (11319, 512, 2048, 0), (11319, 512, 1536, 1),
-                                      (4096, 512, 1536, 0)])
-def test_stream_k_phased_kernel_is_right_and_repeatable(M, N, K, tb):
-    """variant 14: the 256x256 phased kernel as a stream-K kernel (256 workgroups share tiles x K-tiles iterations equally;
-    tails go out as slabs, the workgroup holding k = 0 of a tile adds them and runs the epilogue): equal to an fp32 reference
-    through the residual / bias epilogue, bit-identical from launch to launch, ticket counters left at zero."""
-    ops = _ops()
-    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
-    w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
-    ref = a.float() @ (w.float() if tb else w.float().t())
-    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
-    slab = (torch.empty(64 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(4096, dtype=torch.int32, device="cuda"))
-    slab[0].fill_(0xff)
-    want = ref + bias + res
-    out = torch.full((M, N), float("nan"), device="cuda")
-    ops.gemm(a, w, out, trans_b=bool(tb), bias=bias, residual=res)            # default kernel
-    assert float((out - want).abs().max()) < 1e-5 * float(want.abs().max())
-    try:
-        ops.gemm_set_variant(14)
-        first = None
-        for it in range(6):
-            out = torch.full((M, N), float("nan"), device="cuda")
-            ops.gemm(a, w, out, trans_b=bool(tb), bias=bias, residual=res, slab=slab)
-            assert float((out - want).abs().max()) < 1e-5 * float(want.abs().max()), "launch %d" % it
-            if first is None:
-                first = out
-            else:
-                assert torch.equal(out, first)
-        assert int(slab[1].abs().sum()) == 0
-    finally:
-        ops.gemm_set_variant(5)
 
 
 @pytest.mark.parametrize("M,N,K,split", [(3072, 768, 12800, 3), (768, 3072, 12800, 3), (2304, 768, 12800, 4), (2048, 512, 11319, 6),
