@@ -10,7 +10,10 @@ WN = int(os.environ.get("ILVLM_PK_WN", "2"))
 CASES = [("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 5, 128, 128, 4), ("fc.fwd", 0, 0, 12800, 3072, 768, False, 1, 15, 128, 64 * WN, WN),
          ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 5, 128, 128, 4), ("fc.dgrad", 0, 1, 12800, 768, 3072, False, 1, 15, 128, 64 * WN, WN),
          ("pk.fc.fwd", 0, 0, 11319, 2048, 512, False, 1, 5, 128, 128, 4), ("pk.fc.fwd", 0, 0, 11319, 2048, 512, False, 1, 15, 128, 64 * WN, WN),
-         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 5, 128, 128, 4)]
+         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 5, 128, 128, 4), ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 3, 15, 128, 128, 4),
+         ("fc.wgrad", 1, 1, 3072, 768, 12800, True, 2, 15, 128, 128, 4), ("pk.fc.wgrad", 1, 1, 2048, 512, 11319, True, 6, 15, 128, 128, 4)]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if sys.argv[1] in c[0]]
 for (tag, ta, tb, M, N, K, acc, split, v, bm, bn, nw) in CASES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda").to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)

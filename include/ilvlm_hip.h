@@ -225,6 +225,12 @@ int ilvlm_sparsemax_fwd(const float* z, float* out, int rows, int cols, void* st
 int ilvlm_sparsemax_bwd(const float* out, const float* g, float* dz, int rows, int cols, void* stream);
 int ilvlm_softmax_fwd(const float* z, float* out, int rows, int cols, void* stream);
 int ilvlm_softmax_bwd(const float* out, const float* g, float* dz, int rows, int cols, void* stream);
+/* att_func_type 'sigmoid' (nn.Sigmoid clip_fdt.py:76-78 and the division of the weighted sum by the weights' row sum,
+ * clip_fdt.py:156-157): w = sigmoid(z) (the returned attention weights), wn = w / rowsum (the operand of the weighted
+ * codebook sum), rowsum[row] = sum_c w.  Backward: g = d loss / d wn -> dz. */
+int ilvlm_sigmoid_norm_fwd(const float* z, float* w, float* wn, float* rowsum, int rows, int cols, void* stream);
+int ilvlm_sigmoid_norm_bwd(const float* w, const float* wn, const float* rowsum, const float* g, float* dz, int rows, int cols,
+                           void* stream);
 
 /* ---- y = x / (||x|| + eps) (clip_fdt.py:411-412; clip.py:133-134) ---- */
 int ilvlm_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream);

@@ -16,6 +16,8 @@
 // image_encoder/base_transformer.py:45-48 and text_encoder/base_transformer.py:45-48 (causal mask
 // text_transformer.py:147-153).  The reference's head-averaged attention weights are discarded by its callers
 // (base_transformer.py:59, text_transformer.py:234 unless return_att) and are not produced.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -880,14 +882,14 @@ int launch_fwd_wave(const bf16* qkv, bf16* out, float* lse, int B, int L, int H,
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 2 * ROWS * LDH * 2;
     if (bytes > 64 * 1024) {
-        static bool done = false;   // per instantiation; the attribute is idempotent
-        if (!done) {
-            int rc = set_lds(attn_fwd_wave<NT, NW, true>, bytes, "attention_fwd");
-            if (rc) return rc;
-            rc = set_lds(attn_fwd_wave<NT, NW, false>, bytes, "attention_fwd");
-            if (rc) return rc;
-            done = true;
-        }
+        // once per instantiation, thread-safe: forward runs on the main thread, backward on autograd's worker
+        static std::once_flag once;
+        static int attr_rc = ILVLM_OK;
+        std::call_once(once, [&] {
+            attr_rc = set_lds(attn_fwd_wave<NT, NW, true>, bytes, "attention_fwd");
+            if (!attr_rc) attr_rc = set_lds(attn_fwd_wave<NT, NW, false>, bytes, "attention_fwd");
+        });
+        if (attr_rc) return attr_rc;
     }
     if (causal) hipLaunchKernelGGL((attn_fwd_wave<NT, NW, true>), dim3(B * H), dim3(64 * NW), bytes, s, qkv, out, lse, L, H, 1, seq_offs, q8);
     else hipLaunchKernelGGL((attn_fwd_wave<NT, NW, false>), dim3(B * H), dim3(64 * NW), bytes, s, qkv, out, lse, L, H, 0, seq_offs, q8);
@@ -900,12 +902,10 @@ int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const fl
     constexpr int ROWS = ((NT + 1) & ~1) * 16;
     constexpr int bytes = 3 * ROWS * LDH * 2 + 2 * ROWS * 4;    // 57 KB at 128 tokens, 127 KB at 288
     if (bytes > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            int rc = set_lds(attn_bwd_wave<NT, NW>, bytes, "attention_bwd");
-            if (rc) return rc;
-            done = true;
-        }
+        static std::once_flag once;
+        static int attr_rc = ILVLM_OK;
+        std::call_once(once, [&] { attr_rc = set_lds(attn_bwd_wave<NT, NW>, bytes, "attention_bwd"); });
+        if (attr_rc) return attr_rc;
     }
     hipLaunchKernelGGL((attn_bwd_wave<NT, NW>), dim3(B * H), dim3(64 * NW), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal,
                        seq_offs, q8);
@@ -917,12 +917,10 @@ template <int LP>
 int launch_bwd_tiled_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
                           int causal, hipStream_t s) {
     constexpr int bytes = (2 * LP * LDH + 2 * 32 * LDH + 2 * LP * 40) * 2 + 2 * LP * 4;
-    static bool done = false;
-    if (!done) {
-        int rc = set_lds(attn_bwd_tiled_bf16<LP>, bytes, "attention_bwd_tiled");
-        if (rc) return rc;
-        done = true;
-    }
+    static std::once_flag once;
+    static int attr_rc = ILVLM_OK;
+    std::call_once(once, [&] { attr_rc = set_lds(attn_bwd_tiled_bf16<LP>, bytes, "attention_bwd_tiled"); });
+    if (attr_rc) return attr_rc;
     hipLaunchKernelGGL((attn_bwd_tiled_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
     ILVLM_LAUNCH_CHECK("attention_bwd_tiled");
     return ILVLM_OK;
@@ -970,12 +968,10 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype,
         return ILVLM_OK;
     }
     int bytes = (3 * Lcap * LDF + Lcap * (Lcap + 1)) * 4;
-    static bool done_f = false;
-    if (!done_f) {
-        int rc = set_lds(attn_fwd_f32, 160 * 1024, "attention_fwd_f32");
-        if (rc) return rc;
-        done_f = true;
-    }
+    static std::once_flag once_f;
+    static int attr_rc_f = ILVLM_OK;
+    std::call_once(once_f, [&] { attr_rc_f = set_lds(attn_fwd_f32, 160 * 1024, "attention_fwd_f32"); });
+    if (attr_rc_f) return attr_rc_f;
     hipLaunchKernelGGL(attn_fwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)qkv, (float*)out, lse, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_fwd_f32");
     return ILVLM_OK;
@@ -1029,12 +1025,10 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
         return ILVLM_OK;
     }
     int bytes = (4 * Lcap * LDF + 2 * Lcap * (Lcap + 1) + Lcap) * 4;
-    static bool done_b = false;
-    if (!done_b) {
-        int rc = set_lds(attn_bwd_f32, 160 * 1024, "attention_bwd_f32");
-        if (rc) return rc;
-        done_b = true;
-    }
+    static std::once_flag once_b;
+    static int attr_rc_b = ILVLM_OK;
+    std::call_once(once_b, [&] { attr_rc_b = set_lds(attn_bwd_f32, 160 * 1024, "attention_bwd_f32"); });
+    if (attr_rc_b) return attr_rc_b;
     hipLaunchKernelGGL(attn_bwd_f32, dim3(B * H), dim3(256), bytes, s, (const float*)dout, (const float*)qkv,
                        (const float*)out, lse, (float*)dqkv, L, H, causal, seq_offs);
     ILVLM_LAUNCH_CHECK("attention_bwd_f32");

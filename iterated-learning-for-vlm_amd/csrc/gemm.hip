@@ -1130,6 +1130,57 @@ __device__ __forceinline__ void pk_landed(bf16x8 (&b)[4][2]) {
                  "+v"(b[3][1]));
 }
 
+// single-load forms of pk_dma / pk_load_b for the interleaved main loop (one load behind every group of four MFMAs)
+__device__ __forceinline__ void pk_dma1(pk_i32x4 rs, int voff, int soff, unsigned lds, int ok) {
+    asm volatile(
+        "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lpk_dma1_skip%=\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+        ".Lpk_dma1_skip%=:"
+        :
+        : [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff), [lds] "s"(lds), [ok] "s"(ok)
+        : "scc");
+}
+template <int OFS>
+__device__ __forceinline__ void pk_load_b1(bf16x8& b, pk_i32x4 rs, int voff, int soff, int ok) {
+    asm volatile(
+        "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lpk_b1_skip%=\n\t"
+        "buffer_load_dwordx4 %[b], %[vo], %[rs], %[so] offen offset:%c[ofs]\n\t"
+        ".Lpk_b1_skip%=:"
+        : [b] "=&v"(b)
+        : [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff), [ok] "s"(ok), [ofs] "i"(OFS)
+        : "scc");
+}
+
+// interleaved step body: the 16 (NP = 8) / 12 (NP = 4) loads of the NEXT K-tile are issued one by one behind the groups of
+// four MFMAs of the current one, so that a wave's own matrix pipe has work queued while a load instruction issues (a 1 KiB
+// load holds the wave's instruction stream for ~50-100 cycles; issued as one block in front of the MFMAs they cost a wave
+// ~800 cycles per K-tile without a single MFMA -- in-kernel stamps)
+template <int NP>
+__device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane,
+                                              bf16x8 (&bn)[4][2], pk_i32x4 rsa, int a_voff, int a_soff, int a_jstep, unsigned lds,
+                                              pk_i32x4 rsb, int b_voff, int s0, int s1, int s2, int s3, int ok) {
+    // the A fragment of group g + 1 is requested before the MFMAs of group g (the load statements between them are volatile
+    // asm: the compiler keeps their order, so it cannot hoist the reads itself)
+    bf16x8 fa = p8_frag<false, 128, 64>(as, 0, 0, lane);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int ks = g >> 3, i = g & 7;
+        bf16x8 fn = fa;
+        if (g + 1 < 16) fn = p8_frag<false, 128, 64>(as, ((g + 1) & 7) * 16, ((g + 1) >> 3) * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);          // keeps the read above this group's MFMAs (hipcc sinks it to reuse the register)
+        if (g < NP) pk_dma1(rsa, a_voff, a_soff + g * a_jstep, lds + g * 1024, ok);
+        else if (g < NP + 8) {
+            const int q = g - NP;                       // B load q: column tile q >> 1, k-step q & 1
+            const int so = (q >> 1) == 0 ? s0 : (q >> 1) == 1 ? s1 : (q >> 1) == 2 ? s2 : s3;
+            if (q & 1) pk_load_b1<1024>(bn[q >> 1][1], rsb, b_voff, so, ok);
+            else pk_load_b1<0>(bn[q >> 1][0], rsb, b_voff, so, ok);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], fa, acc[i][j], 0, 0, 0);
+        fa = fn;
+    }
+}
+
 // 64 MFMAs of one K-tile: A fragments from the LDS stage, B fragments from registers (C^T fragments as everywhere else:
 // a lane owns output row (l & 15) and 4 consecutive columns)
 __device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane) {
@@ -1144,7 +1195,7 @@ __device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned ch
 }
 #endif
 
-template <int WN>
+template <int WN, bool IL>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
                                                                   int K, int tiles_m, int tiles_n, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1207,6 +1258,15 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         ILVLM_WG_BARRIER();                                                               \
         STAMP(p2);                                                                        \
         a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;               \
+        if constexpr (IL) {                                                               \
+            STAMP(p3);                                                                    \
+            pk_compute_il<NP>(acc, smem_raw + (CUR_STAGE) * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff, a_jstep,   \
+                              lds0 + (NXT_STAGE) * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                    \
+            PK_KEEP();                                                                    \
+            STAMP(p4);                                                                    \
+            STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_issue, p2, p3); STAMP_ADD(c_comp, p3, p4); \
+            break;                                                                        \
+        }                                                                                 \
         pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0 + (NXT_STAGE) * STAGE, MORE);       \
         pk_load_b(BNXT, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                           \
         STAMP(p3);                                                                        \
@@ -1418,9 +1478,9 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <int WN>
+template <int WN, bool IL>
 int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_pk_kernel<WN>;
+    auto kern = gemm_bf16_pk_kernel<WN, IL>;
     constexpr int ring = 2 * 128 * 64 * 2, epi = WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
@@ -1565,8 +1625,11 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
             const int tn_pk = ceil_div(N, 64 * wn);
             ep.tile_group = (tile_group_env > 0 && K <= tile_kmax_env && tn_pk > tile_group_env) ? tile_group_env : 0;
-            if (wn == 4) return launch_pk<4>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
-            return launch_pk<2>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
+            static const int pk_il = getenv("ILVLM_PK_IL") ? atoi(getenv("ILVLM_PK_IL")) : 1;
+            if (wn == 4) return pk_il ? launch_pk<4, true>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s)
+                                      : launch_pk<4, false>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
+            return pk_il ? launch_pk<2, true>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s)
+                         : launch_pk<2, false>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
         }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU

@@ -270,6 +270,39 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int c = threadIdx.x; c < cols; c += 256) dz[base + c] = out[base + c] * (g[base + c] - s);
 }
 
+// att_func_type 'sigmoid' (reference clip_fdt.py:76, 149, 156-157): att_weight = sigmoid(z); the weighted codebook sum is
+// divided by the row sum of the weights, i.e. att_ft = (att_weight / sum) @ sd.  w = the returned weights, wn = w / sum (the
+// GEMM operand), rsum[row] = sum.
+__global__ __launch_bounds__(256) void sigmoid_norm_fwd_kernel(const float* __restrict__ z, float* __restrict__ w,
+                                                               float* __restrict__ wn, float* __restrict__ rsum, int cols) {
+    __shared__ float scratch[4];
+    const long base = (long)blockIdx.x * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = 1.0f / (1.0f + expf(-z[base + c]));
+        w[base + c] = v;
+        s += v;
+    }
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) rsum[blockIdx.x] = s;
+    for (int c = threadIdx.x; c < cols; c += 256) wn[base + c] = w[base + c] / s;      // own elements: no barrier needed
+}
+// g = d loss / d wn;  dw_i = (g_i - sum_j g_j wn_j) / S;  dz_i = dw_i w_i (1 - w_i)
+__global__ __launch_bounds__(256) void sigmoid_norm_bwd_kernel(const float* __restrict__ w, const float* __restrict__ wn,
+                                                               const float* __restrict__ rsum, const float* __restrict__ g,
+                                                               float* __restrict__ dz, int cols) {
+    __shared__ float scratch[4];
+    const long base = (long)blockIdx.x * cols;
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) dot += g[base + c] * wn[base + c];
+    dot = block_sum_256(dot, scratch);
+    const float inv = 1.0f / rsum[blockIdx.x];
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = w[base + c];
+        dz[base + c] = (g[base + c] - dot) * inv * v * (1.0f - v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // y = x / (||x|| + eps)  (reference clip_fdt.py:411-412, clip.py:133-134); one wave per row
 // ------------------------------------------------------------------------------------------------
@@ -663,6 +696,19 @@ extern "C" int ilvlm_softmax_bwd(const float* out, const float* g, float* dz, in
     ILVLM_REQUIRE(out && g && dz && rows > 0 && cols > 0, "softmax_bwd: bad args");
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, S_, out, g, dz, cols);
     ILVLM_LAUNCH_CHECK("softmax_bwd");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_sigmoid_norm_fwd(const float* z, float* w, float* wn, float* rowsum, int rows, int cols, void* stream) {
+    ILVLM_REQUIRE(z && w && wn && rowsum && rows > 0 && cols > 0, "sigmoid_norm_fwd: bad args");
+    hipLaunchKernelGGL(sigmoid_norm_fwd_kernel, dim3(rows), dim3(256), 0, S_, z, w, wn, rowsum, cols);
+    ILVLM_LAUNCH_CHECK("sigmoid_norm_fwd");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_sigmoid_norm_bwd(const float* w, const float* wn, const float* rowsum, const float* g, float* dz, int rows,
+                                      int cols, void* stream) {
+    ILVLM_REQUIRE(w && wn && rowsum && g && dz && rows > 0 && cols > 0, "sigmoid_norm_bwd: bad args");
+    hipLaunchKernelGGL(sigmoid_norm_bwd_kernel, dim3(rows), dim3(256), 0, S_, w, wn, rowsum, g, dz, cols);
+    ILVLM_LAUNCH_CHECK("sigmoid_norm_bwd");
     return ILVLM_OK;
 }
 extern "C" int ilvlm_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream) {

@@ -863,20 +863,25 @@ class Engine:
             ops.fdt_pool_fwd(scores, mask, pooled, argmax, B, Tn, Cn, math.sqrt(d), float(temperature), pool, seq)
             del scores
         att_w = torch.empty_like(pooled)
+        att_n, rsum = att_w, None       # att_n: the operand of the weighted codebook sum
         if cfg["att_func"] == "sparsemax":
             ops.sparsemax_fwd(pooled, att_w)
         elif cfg["att_func"] == "softmax":
             ops.softmax_fwd(pooled, att_w)
+        elif cfg["att_func"] == "sigmoid":
+            # clip_fdt.py:76,156-157: weights = sigmoid, the weighted sum is divided by the weights' row sum
+            att_n, rsum = torch.empty_like(pooled), _empty((B,), torch.float32, q)
+            ops.sigmoid_norm_fwd(pooled, att_w, att_n, rsum)
         else:
-            raise NotImplementedError("att_func_type=%r has no HIP kernel (supported: sparsemax, softmax)" % cfg["att_func"])
+            raise NotImplementedError("att_func_type=%r (reference: softmax, sigmoid, sparsemax)" % cfg["att_func"])
         # [B,C] x [C,d]: only (B/64)*(d/64) output tiles -> split the 4096-deep reduction over 8 workgroups each
         att_ft = torch.zeros((B, d), dtype=torch.float32, device=q.device)
-        ops.gemm(att_w, sd, att_ft, trans_b=True, accumulate=True, split_k=8 if Cn >= 1024 else 1)
-        return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn, seq) if save else None)
+        ops.gemm(att_n, sd, att_ft, trans_b=True, accumulate=True, split_k=8 if Cn >= 1024 else 1)
+        return att_w, att_ft, ((q, argmax, mask, att_w, float(temperature), B, Tn, seq, att_n, rsum) if save else None)
 
     def fdt_bwd(self, saved, datt_ft):
         """Returns dq [B*Tn, d] in T; accumulates d space_dict."""
-        q, argmax, mask, att_w, temperature, B, Tn, seq = saved
+        q, argmax, mask, att_w, temperature, B, Tn, seq, att_n, rsum = saved
         cfg, Wf, Gr, T = self.cfg, self.Wf, self.Gr, self.T
         sd = Wf["space_dict"]
         Cn, d = sd.shape
@@ -884,9 +889,12 @@ class Engine:
         datt_w = torch.empty_like(att_w)
         ops.gemm(datt_ft, sd, datt_w)                                      # [B,d] . sd[C,d]^T
         if need_sd:
-            ops.gemm(att_w, datt_ft, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True)   # att_w^T datt_ft
+            ops.gemm(att_n, datt_ft, Gr["space_dict"], trans_a=True, trans_b=True, accumulate=True)   # att_n^T datt_ft
         dpooled = torch.empty_like(att_w)
-        (ops.sparsemax_bwd if cfg["att_func"] == "sparsemax" else ops.softmax_bwd)(att_w, datt_w, dpooled)
+        if cfg["att_func"] == "sigmoid":
+            ops.sigmoid_norm_bwd(att_w, att_n, rsum, datt_w, dpooled)
+        else:
+            (ops.sparsemax_bwd if cfg["att_func"] == "sparsemax" else ops.softmax_bwd)(att_w, datt_w, dpooled)
         rows = q.shape[0]
         dscores = _empty((rows, Cn), T, q)
         ops.fdt_pool_bwd(dpooled, argmax, mask, dscores, B, Tn, Cn, math.sqrt(d), temperature, POOLS[cfg["pool"]], seq)

@@ -68,6 +68,8 @@ SIGNATURES = {
     "ilvlm_sparsemax_bwd": [vp, vp, vp, i32, i32, vp],
     "ilvlm_softmax_fwd": [vp, vp, i32, i32, vp],
     "ilvlm_softmax_bwd": [vp, vp, vp, i32, i32, vp],
+    "ilvlm_sigmoid_norm_fwd": [vp, vp, vp, vp, i32, i32, vp],
+    "ilvlm_sigmoid_norm_bwd": [vp, vp, vp, vp, vp, i32, i32, vp],
     "ilvlm_l2norm_fwd": [vp, vp, vp, i32, i32, f32, vp],
     "ilvlm_l2norm_bwd": [vp, vp, vp, vp, i32, i32, f32, vp],
     "ilvlm_logit_scale_fwd": [vp, vp, f32, vp],

@@ -590,6 +590,25 @@ def softmax_bwd(out, g, dz):
     _rows2("softmax_bwd", L.load().ilvlm_softmax_bwd, out, g, dz)
 
 
+def sigmoid_norm_fwd(z, w, wn, rowsum):
+    """w = sigmoid(z), wn = w / rowsum(w) (att_func_type 'sigmoid', clip_fdt.py:76,156-157)"""
+    rows, cols = z.shape
+    for t, nm in ((z, "z"), (w, "w"), (wn, "wn")):
+        _chk(t, "sigmoid_norm_fwd." + nm, torch.float32, (rows, cols))
+    _chk(rowsum, "sigmoid_norm_fwd.rowsum", torch.float32, (rows,))
+    L.check(L.load().ilvlm_sigmoid_norm_fwd(z.data_ptr(), w.data_ptr(), wn.data_ptr(), rowsum.data_ptr(), rows, cols, _stream()),
+            "sigmoid_norm_fwd")
+
+
+def sigmoid_norm_bwd(w, wn, rowsum, g, dz):
+    rows, cols = w.shape
+    for t, nm in ((w, "w"), (wn, "wn"), (g, "g"), (dz, "dz")):
+        _chk(t, "sigmoid_norm_bwd." + nm, torch.float32, (rows, cols))
+    _chk(rowsum, "sigmoid_norm_bwd.rowsum", torch.float32, (rows,))
+    L.check(L.load().ilvlm_sigmoid_norm_bwd(w.data_ptr(), wn.data_ptr(), rowsum.data_ptr(), g.data_ptr(), dz.data_ptr(), rows, cols,
+                                            _stream()), "sigmoid_norm_bwd")
+
+
 def l2norm_fwd(x, y, norm, eps):
     rows, cols = x.shape
     _chk(x, "l2norm.x", torch.float32); _chk(y, "l2norm.y", torch.float32, x.shape); _chk(norm, "l2norm.norm", torch.float32, (rows,))

@@ -24,6 +24,8 @@ FDT_VARIANTS = [
     ("softmax", "mean", 1.0, None),
     ("softmax", "sum", 1.0, None),
     ("sparsemax", "max", 1000.0, 5.0),      # exp(5) > 100: exercises the clamp of logit_scale.exp().data
+    ("sigmoid", "max", 1000.0, None),       # round 3: att_func_type 'sigmoid' (weighted sum divided by the weights' row sum)
+    ("sigmoid", "mean", 1.0, None),
 ]
 
 
