@@ -44,6 +44,9 @@ def parse():
                     help="compute all 77 positions of every caption as the reference does; default: the text tower runs on the "
                          "valid tokens only (rows behind <|endoftext|> never reach the loss; same logits and gradients)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra all-text-positions timing leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the driver-timed legs for BASELINE configs[3] (ViT-L/14 + FDT, bf16, batch 128) and configs[4] "
+                         "(ViT-B/32 fp8) that follow the headline in the default run")
     ap.add_argument("--overlap-adamw", action="store_true",
                     help="per-block AdamW launches issued from inside backward instead of one launch in optimizer.step() "
                          "(bit-identical; measured +-0 on one GPU: the chip is already full during backward)")
@@ -195,6 +198,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(os.environ.get("ILVLM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
+    # who takes part: the world as the process group reports it and every rank's device (a SCALE run proves itself)
+    prop = torch.cuda.get_device_properties(local)
+    me = dict(rank=rank, local_rank=local, device=prop.name, pci_bus_id=getattr(prop, "pci_bus_id", None),
+              uuid=str(getattr(prop, "uuid", "")), cus=prop.multi_processor_count, host=os.uname().nodename)
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+        rccl_world = dist.get_world_size()
+        backend = dist.get_backend()
+    else:
+        devices, rccl_world, backend = [me], 1, None
+
     D.set_random_seed(0)
     model = model_entry(dict(type="clip_fdt_vitb32" if args.model == "vitb32" else "clip_fdt_vitL14",
                              kwargs=fdt_kwargs(args.precision, args.model)))
@@ -242,12 +257,22 @@ def main():
     for _ in range(args.warmup):
         loss = one_step()
     fence()
+    reducer = model.engine.arena.reducer
+    sent0, calls0 = reducer.bytes_sent, reducer.calls
+    reducer.timing = []                         # exposed communication: comm-stream end vs the optimizer's arrival, per step
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     host_dt = time.perf_counter() - t0          # time the host needed to ENQUEUE the steps (no sync yet)
     fence()
     dt = time.perf_counter() - t0
+    comm_stats = dict(grad_bucket=reducer.bucket, grad_algo=reducer.algo,
+                      grad_bytes_per_step=(reducer.bytes_sent - sent0) // args.steps,
+                      grad_collectives_per_step=(reducer.calls - calls0) // args.steps,
+                      exposed_grad_comm_ms_per_step=round(reducer.exposed_ms(), 4),
+                      embedding_exchange="one all_gather_into_tensor of [2,B,512] fp32 forward + one reduce_scatter_tensor of "
+                                         "[W,2,B,512] backward per step" if world > 1 else "none (one rank)")
+    reducer.timing = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,7 +332,7 @@ def main():
         attn_flops = 7 * 2.0 * 64 * (args.batch * v_tok * v_tok * v_heads * v_layers + text_l2 * t_heads * t_layers)
         executed_flops = s["flops"] / nprof + s["f32_flops"] / nprof + attn_flops
         traffic, traffic_src = None, None      # HBM-side bytes per launch of this kernel family from the committed PMC passes
-        for rnd in ("round2", "round1"):
+        for rnd in ("round3", "round2", "round1"):
             try:
                 if args.model != "vitb32":
                     break
@@ -327,7 +352,9 @@ def main():
                                            "per launch incl. Infinity-Cache hits (%s); algorithmic_bytes_per_launch = operands + "
                                            "output + epilogue operands once each, from the launches timed here" % traffic_src,
                             algorithmic_bytes_per_launch=round(s["bytes"] / max(s["launches"], 1)),
-                            kernel="gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step); achieved = their FLOPs / the "
+                            kernel="gemm_bf16_pk_kernel + gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step: the streaming "
+                                   "kernel on fragment-packed weights for forward / input gradients with K >= 768, the "
+                                   "direct-to-LDS kernels for the rest and the weight gradients); achieved = their FLOPs / the "
                                    "sum of their durations with the towers serialised (HIP events on the launch stream)",
                             launches_per_step=s["launches"] // nprof,
                             gemm_ms_per_step=round(s["ms"] / nprof, 3),
@@ -368,6 +395,86 @@ def main():
             hs.append(1000.0 * (time.perf_counter() - t0h))
         if rank == 0:
             print("phase %-40s %7.3f ms" % ("host enqueue of one step, GPU idle", sorted(hs)[2]), file=sys.stderr, flush=True)
+    # ---- driver-timed legs for the other single-GPU forms of BASELINE configs: [3] ViT-L/14 + FDT bf16 at per-GPU batch 128
+    #      and [4] ViT-B/32 fp8 at the headline batch.  Fresh model / optimizer each, the same step and timing contract as
+    #      the headline (every rank runs them: collectives stay matched), own roofline from the GEMM launches of that leg.
+    def extra_leg(model_name, precision, batch):
+        D.set_random_seed(0)
+        m = model_entry(dict(type="clip_fdt_vitb32" if model_name == "vitb32" else "clip_fdt_vitL14",
+                             kwargs=fdt_kwargs(precision, model_name)))
+        m.cuda()
+        dd = D.convert_to_ddp_model(m, local)
+        o = optim_entry(dict(type="AdamW", kwargs=dict(params=param_group_all(dd, PCONFIG)[0], lr=5e-5, weight_decay=0.1,
+                                                       betas=[0.9, 0.98], amsgrad=False, eps=1e-8)))
+        sc = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=o, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
+                                                             warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
+        dd.train()
+        im, tk, pd, ln = synthetic_batch(batch, rank, dev)
+        tx = (tk, pd, ops.PackedSeq(ln, tk.shape[1], dev))
+        st = dict(step=0)
+
+        def step():
+            st["step"] += 1
+            sc.step(st["step"])
+            (li_, lt_), _ = dd(im, tx)
+            ls, tg = crit(li_, lt_)
+            if world > 1:
+                ls = ls / world
+            accuracy(li_, tg, topk=(1, 5))
+            o.zero_grad()
+            ops.clamp_(m.logit_scale.data, 3, 6)
+            ls.backward()
+            o.step()
+            ops.clamp_(m.logit_scale.data, 3, 6)
+            return ls
+        for _ in range(max(args.warmup, 3)):        # fp8: one observing step + one step to fill the gradient history
+            step()
+        fence()
+        t0x = time.perf_counter()
+        for _ in range(args.steps):
+            ls = step()
+        fence()
+        dtx = time.perf_counter() - t0x
+        if world > 1:
+            t = torch.tensor([dtx], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtx = float(t.item())
+        res = dict(ms_per_step=round(1000.0 * dtx / args.steps, 3), value=round(world * batch * args.steps / dtx, 1), unit="pairs/s",
+                   dtype=precision, per_gpu_batch=batch, steps=args.steps, final_loss=round(float(ls.item()) * world, 4),
+                   workload="example/clip_fdt %s + FDT, %s compute / fp32 master weights, full train step incl. AdamW, packed text rows" % (
+                       "ViT-B/32" if model_name == "vitb32" else "ViT-L/14", precision))
+        if not args.no_roofline:
+            m.engine.concurrent_towers = False
+            step()
+            torch.cuda.synchronize()
+            prof = ops.GemmProfiler()
+            ops.set_gemm_profiler(prof)
+            for _ in range(2):
+                step()
+            ops.set_gemm_profiler(None)
+            sm = prof.summary()
+            peak = PEAK_BF16
+            res["roofline"] = dict(bound="mfma", unit="TFLOP/s", peak=peak, achieved=round(sm["flops"] / (sm["ms"] * 1e-3) / 1e12, 2),
+                                   frac=round(sm["flops"] / (sm["ms"] * 1e-3) / 1e12 / peak, 4), launches_per_step=sm["launches"] // 2,
+                                   gemm_ms_per_step=round(sm["ms"] / 2, 3), algorithmic_gflop_per_step=round(sm["flops"] / 2 / 1e9, 1),
+                                   kernel="all MFMA GEMM launches of a step (towers serialised, HIP events on the launch stream), "
+                                          "priced against the dense bf16 peak")
+            if precision == "fp8" and sm["fp8"]["launches"]:
+                f8 = sm["fp8"]
+                a8 = f8["flops"] / (f8["ms"] * 1e-3) / 1e12
+                res["roofline"]["fp8_family"] = dict(achieved=round(a8, 2), peak=PEAK_FP8, frac=round(a8 / PEAK_FP8, 4),
+                                                     launches_per_step=f8["launches"] // 2, ms_per_step=round(f8["ms"] / 2, 3),
+                                                     kernel="the transformer-block GEMMs on OCP fp8 operands, priced against the dense "
+                                                            "fp8 peak")
+        del m, dd, o, sc
+        torch.cuda.empty_cache()
+        return res
+
+    legs_extra = {}
+    if not args.no_extra_legs and args.model == "vitb32" and args.precision == "bf16" and not args.all_text_positions:
+        legs_extra["fp8"] = extra_leg("vitb32", "fp8", args.batch)
+        legs_extra["vitl14"] = extra_leg("vitl14", "bf16", 128)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "vitb32" and args.precision != "fp8":
         cpu = cpu_baseline()
@@ -402,6 +509,8 @@ def main():
             "step_mfma_frac_survey_flops_note": "pairs/s x SURVEY 8(d)'s %.1f GFLOP per pair, which counts all 77 text positions "
                                                 "(more than the packed rows execute)" % (FLOPS_PER_PAIR[args.model] / 1e9),
             "all_text_positions": dense,
+            "fp8": legs_extra.get("fp8"), "vitl14": legs_extra.get("vitl14"),
+            "rccl_world": rccl_world, "dist_backend": backend, "devices": devices, "comm": comm_stats,
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(1000.0 * host_dt / args.steps, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -121,9 +121,10 @@ typedef struct ilvlm_gemm_epilogue {
 
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
-/* bf16 kernel selection (tuning / tests; process-wide atomic): 15 (default) the streaming kernel wherever the epilogue
- * offers b_packed and the direct-to-LDS 128x128 kernel elsewhere; 5 always the direct-to-LDS 128x128 kernel (the A/B
- * reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
+/* bf16 kernel selection (tuning / tests; process-wide atomic): 15 (default) the streaming kernel where the epilogue offers
+ * b_packed and the K-loop is long enough to pay (K >= 768), the two-stage direct-to-LDS kernel for weight gradients and the
+ * single-stage direct-to-LDS 128x128 kernel elsewhere; 16 as 15 but the streaming kernel for every eligible shape (tests);
+ * 5 always the single-stage direct-to-LDS 128x128 kernel (the A/B reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
  * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
@@ -385,8 +386,8 @@ int ilvlm_attention_packed_bwd(const void* dout, const void* qkv, const void* ou
                                int B, int L, int Lcap, int H, int causal, const int32_t* seq_offs, void* stream);
 /* fp8 mode: the same kernels also emit the fp8 copy their consumer GEMM reads and raise q_amax[0] to max|value| (the copy
  * quantises the bf16-rounded value with q_scale[0]; out8 / dqkv8 NULL = observe the amax only).  Forward: out8 [rows, E]
- * e4m3 of `out`.  Backward: dqkv8 [rows, 3E] e5m2 of `dqkv`; dqkv itself may be NULL when every consumer reads the copy;
- * sequences up to 128 tokens.  bf16 only.  seq_offs NULL = dense rows (Lcap ignored). */
+ * e4m3 of `out`.  Backward: dqkv8 [rows, 3E] e5m2 of `dqkv`; dqkv itself may be NULL when every consumer reads the copy
+ * (every sequence length the bf16 kernels take, up to 288 tokens).  bf16 only.  seq_offs NULL = dense rows (Lcap ignored). */
 int ilvlm_attention_fwd_q8(const void* qkv, void* out, float* lse, int dtype, int B, int L, int Lcap, int H, int causal,
                            const int32_t* seq_offs, void* out8, const float* q_scale, float* q_amax, void* stream);
 int ilvlm_attention_bwd_q8(const void* dout, const void* qkv, const void* out, const float* lse, void* dqkv, int dtype, int B,

@@ -10,9 +10,9 @@ Here: ONE fused all-gather of [2,B,D] forward, ONE reduce-scatter of [W,2,B,D] b
 all-reduce + slice of the reference at 1/W of the traffic), and the gradient mean of ranges of the flat gradient arena
 on a side stream, per transformer block as soon as the block's backward is complete (prototype/utils/torch_ddp_dist.py).
 
-Gradient buckets.  `ILVLM_GRAD_BUCKET=bf16` (default in bf16 mode, see NativeDDP) sends the mean in bf16: the fp32 range is
-cast into a bf16 bucket on the communication stream, reduced, and widened back into the arena -- 309 MB instead of 618 MB
-per step on the wire.  `ILVLM_GRAD_ALGO=rs_ag` expresses the mean as reduce-scatter + all-gather (each rank owns 1/W of the
+Gradient buckets.  Default: fp32, the reference's arithmetic.  `ILVLM_GRAD_BUCKET=bf16` (opt-in, see NativeDDP) sends the
+mean in bf16: the fp32 range is cast into a bf16 bucket on the communication stream, reduced, and widened back into the
+arena -- 309 MB instead of 618 MB per step on the wire, at one bf16 rounding of every averaged gradient.  `ILVLM_GRAD_ALGO=rs_ag` expresses the mean as reduce-scatter + all-gather (each rank owns 1/W of the
 bucket), the formulation whose two halves RCCL can run as direct exchanges over the 7 xGMI links of the full mesh;
 `allreduce` (default) leaves the choice to RCCL.
 
@@ -112,6 +112,8 @@ class GradReducer:
             raise ValueError("GradReducer: bucket must be fp32|bf16 and algo allreduce|rs_ag, got %r %r" % (self.bucket, self.algo))
         self._staging = {}          # chunk elements -> reusable bf16 / shard buffers (allocated on the comm stream)
         self.bytes_sent = 0         # bytes handed to the collectives since construction (tests)
+        self.calls = 0              # collective calls since construction
+        self.timing = None          # set to [] (bench.py): wait() records (consumer-stream event, comm-stream event) pairs
 
     def _buf(self, key, n, dtype):
         b = self._staging.get((key, dtype))
@@ -124,6 +126,7 @@ class GradReducer:
         """in-place mean over ranks of the 1-D tensor t (fp32 or bf16)"""
         W = self.W
         self.bytes_sent += t.numel() * t.element_size()
+        self.calls += 1
         if self.algo == "rs_ag" and _has_reduce_scatter():
             n = t.numel()
             per = (n + W - 1) // W
@@ -172,5 +175,19 @@ class GradReducer:
     def wait(self):
         """Make the current stream wait for every enqueued reduction (call before the optimizer reads gradients)."""
         if self.pending and self.cuda:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self.timing is not None:
+                # exposed communication of this step = how much later the communication stream finishes than the consumer
+                # stream reaches this wait (both events on their own streams; read after a synchronise)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                e1.record(self.stream)
+                self.timing.append((e0, e1))
+            cur.wait_stream(self.stream)
         self.pending = False
+
+    def exposed_ms(self):
+        """mean over the recorded waits of max(0, comm-stream end - consumer arrival) in ms (after a device synchronise)"""
+        if not self.timing:
+            return 0.0
+        return sum(max(0.0, a.elapsed_time(b)) for a, b in self.timing) / len(self.timing)

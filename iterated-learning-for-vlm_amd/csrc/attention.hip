@@ -498,7 +498,10 @@ __device__ __forceinline__ void load_rows(bf16* dst, const bf16* src, long row_s
 template <int LP>
 __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restrict__ dout, const bf16* __restrict__ qkv,
                                                            const bf16* __restrict__ outp, const float* __restrict__ lse,
-                                                           bf16* __restrict__ dqkv, int L, int H, int causal) {
+                                                           bf16* __restrict__ dqkv, int L, int H, int causal, AttnQ8 q8) {
+    // fp8 mode: e5m2 copy of dqkv emitted with the stores (dqkv itself may then be null), amax raised once per wave
+    const float qs = q8.out8 ? q8.scale[0] : 1.f;
+    float qm = 0.f;
     constexpr int NQ = LP / 16, KB = 32, LDB = KB + 8, NA = (NQ + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Qs = (bf16*)smem_raw;            // [LP][72]
@@ -631,7 +634,9 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restric
             const int key = kb * KB + kt * 16 + c16;
             if (key < L) {
                 bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
-                *(bf16x4*)(dqkv + ((long)b * L + key) * rs + (which == 0 ? 2 * E : E) + h * HD + dt * 16 + 4 * g) = ov;
+                const long off = ((long)b * L + key) * rs + (which == 0 ? 2 * E : E) + h * HD + dt * 16 + 4 * g;
+                if (dqkv) *(bf16x4*)(dqkv + off) = ov;
+                if (q8.amax) q8_emit<1>(q8.out8, off, ov, qs, qm);
             }
         }
         __syncthreads();   // K/V/P/dS of this block are dead: the next block may overwrite them
@@ -644,9 +649,15 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_bf16(const bf16* __restric
             for (int d = 0; d < 4; ++d) {
                 bf16x4 ov = {(bf16)(dq[a][d][0] * 0.125f), (bf16)(dq[a][d][1] * 0.125f), (bf16)(dq[a][d][2] * 0.125f),
                              (bf16)(dq[a][d][3] * 0.125f)};
-                *(bf16x4*)(dqkv + ((long)b * L + q) * rs + h * HD + d * 16 + 4 * g) = ov;
+                const long off = ((long)b * L + q) * rs + h * HD + d * 16 + 4 * g;
+                if (dqkv) *(bf16x4*)(dqkv + off) = ov;
+                if (q8.amax) q8_emit<1>(q8.out8, off, ov, qs, qm);
             }
         }
+    }
+    if (q8.amax) {                 // every wave reaches this point
+        qm = wave_max(qm);
+        if (lane == 0) fp8_amax_raise(q8.amax, qm);
     }
 }
 
@@ -915,13 +926,13 @@ int launch_bwd_wave(const bf16* dout, const bf16* qkv, const bf16* out, const fl
 
 template <int LP>
 int launch_bwd_tiled_bf16(const bf16* dout, const bf16* qkv, const bf16* out, const float* lse, bf16* dqkv, int B, int L, int H,
-                          int causal, hipStream_t s) {
+                          int causal, hipStream_t s, AttnQ8 q8) {
     constexpr int bytes = (2 * LP * LDH + 2 * 32 * LDH + 2 * LP * 40) * 2 + 2 * LP * 4;
     static std::once_flag once;
     static int attr_rc = ILVLM_OK;
     std::call_once(once, [&] { attr_rc = set_lds(attn_bwd_tiled_bf16<LP>, bytes, "attention_bwd_tiled"); });
     if (attr_rc) return attr_rc;
-    hipLaunchKernelGGL((attn_bwd_tiled_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal);
+    hipLaunchKernelGGL((attn_bwd_tiled_bf16<LP>), dim3(B * H), dim3(256), bytes, s, dout, qkv, out, lse, dqkv, L, H, causal, q8);
     ILVLM_LAUNCH_CHECK("attention_bwd_tiled");
     return ILVLM_OK;
 }
@@ -990,8 +1001,7 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
                               int B, int L, int Lcap, int H, int causal, const int* seq_offs, void* stream,
                               AttnQ8 q8 = AttnQ8{nullptr, nullptr, nullptr}) {
     ILVLM_REQUIRE(dout && qkv && out && lse && (dqkv || q8.out8), "attention_bwd: null pointer");
-    ILVLM_REQUIRE(!q8.amax || (dtype == ILVLM_BF16 && Lcap <= 128 && (!q8.out8 || q8.scale)),
-                  "attention_bwd: the fp8 copy needs bf16, a scale and sequences up to 128 tokens (wave-per-tile kernel)");
+    ILVLM_REQUIRE(!q8.amax || (dtype == ILVLM_BF16 && (!q8.out8 || q8.scale)), "attention_bwd: the fp8 copy needs bf16 and a scale");
     ILVLM_REQUIRE(B > 0 && L > 0 && H > 0 && Lcap > 0 && Lcap <= L, "attention_bwd: bad shape B=%d L=%d Lcap=%d H=%d", B, L, Lcap, H);
     ILVLM_REQUIRE(!seq_offs || Lcap <= (dtype == ILVLM_BF16 ? 128 : 80), "attention_bwd: packed rows support sequences up to 128 (bf16) / 80 (f32) tokens");
     hipStream_t s = (hipStream_t)stream;
@@ -1012,9 +1022,9 @@ static int attention_bwd_impl(const void* dout, const void* qkv, const void* out
             // (425 us against 325 us for the key-block kernel below at L = 257); the forward does profit (190 -> 117 us)
             default: break;
         }
-        if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s);
-        if (L <= 224) return launch_bwd_tiled_bf16<224>(d, q, o, lse, dq, B, L, H, causal, s);
-        return launch_bwd_tiled_bf16<288>(d, q, o, lse, dq, B, L, H, causal, s);
+        if (L <= 192) return launch_bwd_tiled_bf16<192>(d, q, o, lse, dq, B, L, H, causal, s, q8);
+        if (L <= 224) return launch_bwd_tiled_bf16<224>(d, q, o, lse, dq, B, L, H, causal, s, q8);
+        return launch_bwd_tiled_bf16<288>(d, q, o, lse, dq, B, L, H, causal, s, q8);
     }
     ILVLM_REQUIRE(dtype == ILVLM_F32, "attention_bwd: bad dtype %d", dtype);
     if (Lcap > 80) {

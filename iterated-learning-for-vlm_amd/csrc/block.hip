@@ -336,7 +336,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     TRY(linear_bwd(b, T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT,
                    b->out_wpt));
-    if (f8on && Lq <= 128) {     // the wave-per-tile backward emits the e5m2 copy of dqkv itself
+    if (f8on) {                  // the attention backward kernels emit the e5m2 copy of dqkv themselves (all sequence lengths)
         if (f8wg) dqkv = nullptr;
         TRY(ilvlm_attention_bwd_q8(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, dqkv8, sc + F8_DQKV,
                                    am + F8_DQKV, s));

@@ -1505,7 +1505,8 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 // bf16 kernel selection (a tuning / test hook, ilvlm_gemm_set_variant):
 //   15 (default) = the streaming kernel (weights pre-packed in fragment order, gemm_bf16_pk_kernel) wherever the caller
 //                  offers a packed copy of B, the direct-to-LDS 128x128 kernel everywhere else;
-//    5           = always the direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
+//   16           = as 15, but the streaming kernel for EVERY eligible shape with a packed B (tests: short K-loops);
+//    5           = always the single-stage direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
 //    0           = the register-staged general kernel only.
 // The tilings and pipelines that rounds 1 and 2 measured and lost with (64x128, 256x128 3-stage, 256x256 phased, stream-K,
 // persistent, 2-/3-deep rings, 128-deep K-tiles) live in the git history; DESIGN.md section 6 has their numbers.
@@ -1619,9 +1620,14 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bool fast = (variant != 0 || epi->pool_out) && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
         // streaming kernel: the caller offers B in fragment order (weights); A must be K-contiguous, whole K-tiles
-        if (variant == 15 && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
+        // Per-shape choice, measured cold-cache per launch (benchmarks/gemm_bench.py, profiles/round3/gemm_bench.txt): the
+        // streaming kernel wins where the K-loop is long enough to amortise its two-deep prologue (K >= 768: +5..11 % on the
+        // ViT-B/32 shapes with 128x256 tiles) and loses 7..12 % on the K = 512 shapes of the text tower (8 K-tiles), which
+        // keep the direct-to-LDS kernel.
+        static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 768;
+        if ((variant == 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
             (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
-            static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 2;
+            static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 4;
             const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
             const int tn_pk = ceil_div(N, 64 * wn);
             ep.tile_group = (tile_group_env > 0 && K <= tile_kmax_env && tn_pk > tile_group_env) ? tile_group_env : 0;
@@ -1638,7 +1644,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             // t is multiplied (64 KiB of LDS, two workgroups per CU).  Round 2 measured this form 3 % SLOWER; that build
             // was not pipelined at all (compiler-inserted vmcnt(0) behind the DMA builtin, see DmaOperand::issue).
             static const int wgrad_stages = getenv("ILVLM_WGRAD_STAGES") ? atoi(getenv("ILVLM_WGRAD_STAGES")) : 2;
-            if (!swap && trans_a && trans_b && wgrad_stages == 2 && variant != 5)
+            if (!swap && trans_a && trans_b && wgrad_stages == 2 && variant >= 15)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
 #define ILVLM_DMA(TA, TB)                                                                                            \
     return swap ? launch_dma<TA, TB, true, 128, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s)               \
@@ -1675,7 +1681,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 15, "gemm_set_variant: 0, 5 or 15");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 15 || variant == 16, "gemm_set_variant: 0, 5, 15 or 16");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }

@@ -5,8 +5,9 @@ One process per GPU, torchrun env contract (RANK / LOCAL_RANK / WORLD_SIZE / MAS
 gradient averaging is done on the flat gradient arena: each transformer block's range is reduced on a side stream as
 soon as that block's backward is complete (the two towers announce their blocks from their own streams), the rest of
 the text side when the text backward ends and whatever is left at the end; unused and frozen parameters ride along as
-zeros (the reference needs find_unused_parameters=True for them).  In bf16 mode the buckets travel in bf16
-(comm.GradReducer; ILVLM_GRAD_BUCKET=fp32 restores fp32 buckets), fp32 mode reduces fp32 as the reference does."""
+zeros (the reference needs find_unused_parameters=True for them).  The gradient mean is taken in fp32, as the reference's
+DDP does; ILVLM_GRAD_BUCKET=bf16 opts into bf16 buckets (half the bytes on the wire, one bf16 rounding of every averaged
+gradient; tests/test_comm_gloo.py bounds the effect on a two-rank trajectory)."""
 import os
 import random
 
@@ -66,7 +67,9 @@ class NativeDDP(nn.Module):
         arena = module._eng.arena
         if comm._active(comm.world()[1]):
             distributed.broadcast(arena.P, 0)      # ONE flattened broadcast (reference: one per state_dict tensor)
-        bucket = os.environ.get("ILVLM_GRAD_BUCKET", "fp32" if module._eng.precision == "fp32" else "bf16")
+        bucket = os.environ.get("ILVLM_GRAD_BUCKET", "fp32")       # bf16 buckets are opt-in (not the reference's arithmetic)
+        if module._eng.precision == "fp32":
+            bucket = "fp32"
         arena.reducer = comm.GradReducer(arena.G, bucket=bucket)
         self._done = []                            # ranges already reduced in this backward
         object.__setattr__(module, "_grad_sync", self._on_sync)

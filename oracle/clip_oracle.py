@@ -81,6 +81,59 @@ def linear(x, w, b=None):
 
 
 # --------------------------------------------------------------------------------------
+# fp8 control (BASELINE configs[4]; the reference has no fp8 path -- this emulates what the fp8 MODE of the product
+# computes, so that tests can tell the dtype's error from a kernel's).  Inside `with fp8_blocks():` the four linears of
+# every residual attention block (in_proj, out_proj, c_fc, c_proj: exactly the GEMMs the product runs on fp8 operands) take
+# OCP e4m3 activations and weights in the forward pass and e5m2 gradients in both backward products, each tensor with
+# its own scale = format max / amax (the steady state of the product's delayed scaling when the batch repeats); products
+# exact, sums fp32.  Combine with rounding(bf16_ste) for the bf16 storage of everything else.
+# --------------------------------------------------------------------------------------
+_FP8 = False
+
+
+def _q8(t, dtype, fmax):
+    amax = float(t.detach().abs().max())
+    if amax == 0.0 or not math.isfinite(amax):
+        return t
+    s = fmax / amax
+    return (t * s).clamp(-fmax, fmax).to(dtype).to(t.dtype) / s
+
+
+class _Fp8Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x8, w8 = _q8(x, torch.float8_e4m3fn, 448.0), _q8(w, torch.float8_e4m3fn, 448.0)
+        ctx.save_for_backward(x8, w8)
+        return x8 @ w8.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x8, w8 = ctx.saved_tensors
+        g8 = _q8(dy, torch.float8_e5m2, 57344.0)
+        dx = g8 @ w8
+        dw = g8.reshape(-1, g8.shape[-1]).t() @ x8.reshape(-1, x8.shape[-1])
+        return dx, dw
+
+
+class fp8_blocks(object):
+    def __enter__(self):
+        global _FP8
+        self.prev, _FP8 = _FP8, True
+
+    def __exit__(self, *a):
+        global _FP8
+        _FP8 = self.prev
+
+
+def block_linear(x, w, b=None):
+    """the four GEMMs of a residual attention block: fp8 operands under fp8_blocks(), else linear()"""
+    if not _FP8:
+        return linear(x, w, b)
+    y = _Fp8Linear.apply(x, w)
+    return y if b is None else y + b
+
+
+# --------------------------------------------------------------------------------------
 # transformer
 # --------------------------------------------------------------------------------------
 def causal_mask(L, dtype=torch.float32):
@@ -98,7 +151,7 @@ def mha(x, in_w, in_b, out_w, out_b, heads, causal):
     """
     B, L, E = x.shape
     hd = E // heads
-    qkv = Q(linear(x, in_w, in_b))
+    qkv = Q(block_linear(x, in_w, in_b))
     q, k, v = qkv.split(E, dim=-1)
     q = q.reshape(B, L, heads, hd).transpose(1, 2) * math.sqrt(1.0 / hd)
     k = k.reshape(B, L, heads, hd).transpose(1, 2)
@@ -108,7 +161,7 @@ def mha(x, in_w, in_b, out_w, out_b, heads, causal):
         s = s + causal_mask(L, s.dtype)
     p = torch.softmax(s, dim=-1)
     o = (Q(p) @ v).transpose(1, 2).reshape(B, L, E)
-    return linear(o, out_w, out_b)
+    return block_linear(o, out_w, out_b)
 
 
 def resblock(x, p, pre, heads, causal):
@@ -117,8 +170,8 @@ def resblock(x, p, pre, heads, causal):
     x = x + mha(h, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"],
                 p[pre + "attn.out_proj.weight"], p[pre + "attn.out_proj.bias"], heads, causal)
     h = layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
-    h = quick_gelu(linear(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"]))
-    return x + linear(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"])
+    h = quick_gelu(block_linear(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"]))
+    return x + block_linear(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"])
 
 
 def n_layers(p, pre):

@@ -84,11 +84,17 @@ def _w1_worker(rank, world, port, ret):
                     (64 * 999 + flat.numel() - 64 * 1000) * (2 if bucket == "bf16" else 4))
         # --- a full data-parallel step through NativeDDP (init broadcast, per-block reductions from two tower streams, the
         #     embedding exchange inside forward / backward) equals the step without the wrapper
-        for precision in ("fp32", "bf16"):
+        for precision in ("fp32", "bf16", "bf16_optin"):
+            # bf16 mode reduces fp32 buckets by default (the reference's arithmetic); ILVLM_GRAD_BUCKET=bf16 opts in
+            os.environ.pop("ILVLM_GRAD_BUCKET", None)
+            if precision == "bf16_optin":
+                os.environ["ILVLM_GRAD_BUCKET"] = "bf16"
+            prec = precision.split("_")[0]
             comm.force_collectives(False)
-            _, li0, g0 = _step(precision, False)
+            _, li0, g0 = _step(prec, False)
             comm.force_collectives(True)
-            model, li1, g1 = _step(precision, True)
+            model, li1, g1 = _step(prec, True)
+            os.environ.pop("ILVLM_GRAD_BUCKET", None)
             same = bool(torch.equal(li0, li1))
             worst = 0.0
             for n in g0:
@@ -112,9 +118,12 @@ def test_rccl_collective_branch_at_world_size_one():
     same, worst, bucket, sent = out["ddp_fp32"]
     assert same and bucket == "fp32" and sent > 0
     assert worst < 1e-4, worst            # fp32 atomics order only (the mean over one rank is the identity)
-    same, worst, bucket, sent = out["ddp_bf16"]
-    assert same and bucket == "bf16" and sent > 0
-    assert worst < 1.2e-2, worst          # one bf16 rounding of every gradient element (2^-8 relative) + atomics order
+    same, worst, bucket, sent32 = out["ddp_bf16"]
+    assert same and bucket == "fp32" and sent32 > 0     # default in bf16 mode: fp32 buckets
+    assert worst < 2e-2, worst            # atomics order of bf16-rounded products only
+    same, worst, bucket, sent = out["ddp_bf16_optin"]
+    assert same and bucket == "bf16" and 0 < sent == sent32 // 2
+    assert worst < 2.4e-2, worst          # + one bf16 rounding of every gradient element (2^-8 relative)
 
 
 def _w2_worker(rank, world, port, ret):

@@ -160,11 +160,56 @@ def _tiny(precision, seed=11):
     return model.cuda().train(), c
 
 
+def _cos(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def _oracle_step(p0, img, tok, mask, cfg, names, fp8):
+    """fp32 oracle step (fp8 = False) or the fp8-mode control (fp8 = True): the SAME oracle with e4m3 / e5m2 operands in the
+    four GEMMs of every residual attention block and bf16 operands elsewhere (oracle/clip_oracle.py: fp8_blocks, rounding)"""
+    import contextlib
+    p = {k: v.detach().clone().requires_grad_(k in names) for k, v in p0.items()}
+    with contextlib.ExitStack() as st:
+        if fp8:
+            st.enter_context(O.rounding(O.bf16_ste))
+            st.enter_context(O.fp8_blocks())
+        o = O.clip_fdt_forward(p, img, tok, mask, cfg)
+        loss, _ = O.info_nce(o["logits_i"], o["logits_t"])
+        loss.backward()
+    return o["logits_i"].detach(), {n: p[n].grad.detach() for n in names}
+
+
+# The fp8 tolerances are CONTROLLED, not measured-and-frozen (round 2 asserted min cos > 0.8 / 0.85 because that is what the
+# kernels gave): the HIP fp8 gradients must point at the fp32 oracle's at least as well as the fp8-operand oracle's do,
+# minus MARGIN; the logits error may be CTRL x the control's + FLOOR (the pattern of tests/test_parity_bf16_gpu.py).
+MARGIN, CTRL, FLOOR = 0.03, 3.0, 2e-3
+
+
+def _check_against_control(tag, li_hip, g_hip, ref, ctl):
+    (li_ref, g_ref), (li_ctl, g_ctl) = ref, ctl
+    sc = float(li_ref.abs().max())
+    e_hip = float((li_hip.float().cpu() - li_ref).abs().max()) / sc
+    e_ctl = float((li_ctl - li_ref).abs().max()) / sc
+    ch = {n: _cos(g_hip[n], g_ref[n]) for n in g_ref}
+    cc = {n: _cos(g_ctl[n], g_ref[n]) for n in g_ref}
+    worst = min(ch, key=lambda n: ch[n] - cc[n])
+    med = lambda d: sorted(d.values())[len(d) // 2]
+    print("%s: logits error HIP fp8 %.3e, fp8-operand oracle %.3e; gradient cosine vs fp32 oracle: HIP min %.4f median %.4f, "
+          "control min %.4f median %.4f; largest shortfall %.4f (%s)" % (tag, e_hip, e_ctl, min(ch.values()), med(ch),
+                                                                        min(cc.values()), med(cc), cc[worst] - ch[worst], worst))
+    assert e_hip <= CTRL * e_ctl + FLOOR
+    for n in g_ref:
+        assert ch[n] >= cc[n] - MARGIN, "fp8 gradient of %s: cos %.4f, the dtype's own (control) %.4f" % (n, ch[n], cc[n])
+    assert med(ch) >= med(cc) - MARGIN / 2
+
+
 def test_fp8_mode_tiny_model_tracks_bf16():
     """fp8 mode on the tiny golden geometry: the first step only observes (bf16 kernels, identical to bf16 mode), from the
-    second step on the block GEMMs run in fp8; logits stay within fp8's accuracy of the bf16 model, gradients keep their
-    direction, scales are derived from the observed amaxes"""
-    from detfill import det_images, det_tokens
+    second step on the block GEMMs run in fp8; scales are derived from the observed amaxes; logits and the gradients of every
+    block weight are as close to the fp32 oracle as the fp8-operand oracle (the dtype's own error) is"""
+    from configs import CFG, FDT_VARIANTS, oracle_cfg, state_shapes
+    from detfill import det_images, det_tokens, det_state
     from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
     m8, c = _tiny("fp8")
     mb, _ = _tiny("bf16")
@@ -184,54 +229,176 @@ def test_fp8_mode_tiny_model_tracks_bf16():
                                                     if p.grad is not None}))
         outs[name] = res
     f8 = m8.engine.fp8
-    assert f8 is not None and f8.active and f8.steps == 3
+    assert f8 is not None and f8.active and f8.steps == 3 and f8.bwd_seen == 3
     assert torch.equal(outs["fp8"][0][0], outs["bf16"][0][0])          # observing step == bf16 step
     assert float(f8.scale.min()) > 0 and bool((f8.scale != 1).any())
-    ref = outs["bf16"][2][0]
-    err = float((outs["fp8"][2][0] - ref).abs().max() / ref.abs().max())
-    assert err < 5e-2, err
-    cos = []
-    for n, g in outs["bf16"][2][1].items():
-        if "resblocks" in n and n.endswith("weight") and g.dim() == 2:
-            a, b = outs["fp8"][2][1][n].double().flatten(), g.double().flatten()
-            cos.append(float((a * b).sum() / (a.norm() * b.norm())))
-    # e5m2 gradients carry 2 mantissa bits: direction is kept, single weights of this tiny model lose ~10 % in cosine
-    assert min(cos) > 0.8 and sorted(cos)[len(cos) // 2] > 0.95, (min(cos), sorted(cos)[len(cos) // 2])
+    names = [n for n, g in outs["bf16"][2][1].items() if "resblocks" in n and n.endswith("weight") and g.dim() == 2]
+    p0 = {k: torch.from_numpy(a) for k, a in det_state(state_shapes(c, True), 11).items()}
+    cfg = oracle_cfg(c, FDT_VARIANTS[0])
+    args = (img.cpu(), torch.from_numpy(tok), torch.from_numpy(mask), cfg, names)
+    _check_against_control("tiny model", outs["fp8"][2][0], outs["fp8"][2][1], _oracle_step(p0, *args, fp8=False),
+                           _oracle_step(p0, *args, fp8=True))
 
 
 def test_fp8_mode_vitl14_tracks_bf16():
     """fp8 mode at the ViT-L/14 + FDT geometry (width 1024, 257 tokens: the forward attention emits the e4m3 copy itself,
-    the key-block backward falls back to the separate quantise pass of dqkv), batch 8: logits stay within fp8's accuracy
-    of the bf16 model, sampled weight gradients keep their direction"""
+    the key-block backward its e5m2 copy), batch 8, 24 layers of e5m2 gradients: logits and sampled weight gradients of
+    blocks 0 / 11 / 23 against the fp32 oracle, bounded by what the fp8-operand oracle itself loses"""
     import bench as B
     from ilvlm_amd.prototype.model import model_entry
     from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
     images, tokens, pad, lens = B.synthetic_batch(8, 0, "cuda")
-    outs = {}
-    for prec in ("fp8", "bf16"):
-        torch.manual_seed(0)
-        m = model_entry(dict(type="clip_fdt_vitL14", kwargs=B.fdt_kwargs(prec, "vitl14"))).cuda().train()
-        for it in range(2):
-            (li, lt), _ = m(images, (tokens, pad, lens))
-            loss, _ = ClipInfoCELoss()(li, lt)
-            m.zero_grad()
-            loss.backward()
+    torch.manual_seed(0)
+    m = model_entry(dict(type="clip_fdt_vitL14", kwargs=B.fdt_kwargs("fp8", "vitl14")))
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    for it in range(2):
+        (li, lt), _ = m(images, (tokens, pad, lens))
+        loss, _ = ClipInfoCELoss()(li, lt)
+        m.zero_grad()
+        loss.backward()
+    torch.cuda.synchronize()
+    assert m.engine.fp8.active
+    g_hip = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()
+             if p.grad is not None and ("resblocks.0." in n or "resblocks.11." in n or "resblocks.23." in n) and p.dim() == 2}
+    assert len(g_hip) >= 16
+    names = list(g_hip)
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 8))
+    cfg = dict(v_heads=16, t_heads=12, temperature=1000.0, att_func="sparsemax", pool="max")
+    args = (images.cpu(), tokens.cpu(), pad.cpu(), cfg, names)
+    _check_against_control("ViT-L/14 B=8", li.detach(), g_hip, _oracle_step(p0, *args, fp8=False), _oracle_step(p0, *args, fp8=True))
+
+
+def test_fp8_scales_follow_an_amax_jump_without_overflow():
+    """delayed scaling under a sudden change: ln_1's gain of one block is multiplied by 100 for one step (the in-projection's
+    input jumps 100 x against a scale derived from the history).  That step saturates instead of overflowing (finite
+    logits, loss and gradients), its amax is recorded, and the very next step's scale has followed the jump."""
+    from detfill import det_images, det_tokens
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    m, c = _tiny("fp8")
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 5)).cuda()
+    tok, mask = det_tokens(c["batch"], c["ctx"], 5)
+    texts = (torch.from_numpy(tok), torch.from_numpy(mask))
+
+    def step():
+        (li, lt), _ = m(img, texts)
+        loss, _ = ClipInfoCELoss()(li, lt)
+        m.zero_grad()
+        loss.backward()
         torch.cuda.synchronize()
-        grads = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()
-                 if p.grad is not None and ("resblocks.0." in n or "resblocks.11." in n or "resblocks.23." in n) and p.dim() == 2}
-        outs[prec] = (li.detach().float().cpu(), grads)
-        if prec == "fp8":
-            assert m.engine.fp8.active
-        del m
-    ref = outs["bf16"][0]
-    err = float((outs["fp8"][0] - ref).abs().max() / ref.abs().max())
-    assert err < 5e-2, err
-    cos = []
-    for n, g in outs["bf16"][1].items():
-        a, b = outs["fp8"][1][n].double().flatten(), g.double().flatten()
-        cos.append(float((a * b).sum() / (a.norm() * b.norm())))
-    # measured: min 0.926, median 0.946 over 20 matrices of blocks 0 / 11 / 23 (24 layers of e5m2 gradients at batch 8)
-    assert len(cos) >= 16 and min(cos) > 0.85 and sorted(cos)[len(cos) // 2] > 0.92, (min(cos), sorted(cos)[len(cos) // 2])
+        grads = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+        return li, loss, grads
+    for _ in range(3):
+        step()
+    f8 = m.engine.fp8
+    assert f8.active
+    pre = "visual.transformer.resblocks.0."
+    slot = f8.slots[pre + "h1"]
+    s_before = float(f8.scale[slot])
+    g = m.visual.transformer.resblocks[0].ln_1.weight
+    with torch.no_grad():
+        g.mul_(100.0)
+    li, loss, grads = step()                     # quantised with the OLD scale: saturates at +-448 / scale
+    assert bool(torch.isfinite(li).all()) and bool(torch.isfinite(loss)) and bool(torch.isfinite(grads).all())
+    with torch.no_grad():
+        g.div_(100.0)
+    li, loss, grads = step()                     # begin_step folded the jump's amax into the history
+    s_after = float(f8.scale[slot])
+    assert s_after < s_before / 50, (s_before, s_after)
+    assert bool(torch.isfinite(li).all()) and bool(torch.isfinite(grads).all())
+    for _ in range(f8.HIST + 1):                 # the jump leaves the history window again
+        step()
+    assert float(f8.scale[slot]) > s_before / 2
+
+
+def test_fp8_weight_copies_follow_a_text_encoder_reset():
+    """iterated learning under fp8 (train_solver.py:545-557): reset_text_encoder() re-initialises the text tower's fp32 masters
+    behind Fp8State; the next training forward must run on e4m3 copies of the NEW weights (and their transposes), quantised
+    with the scale then in force"""
+    from detfill import det_images, det_tokens
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    m, c = _tiny("fp8")
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 5)).cuda()
+    tok, mask = det_tokens(c["batch"], c["ctx"], 5)
+    texts = (torch.from_numpy(tok), torch.from_numpy(mask))
+
+    def step():
+        (li, lt), _ = m(img, texts)
+        loss, _ = ClipInfoCELoss()(li, lt)
+        m.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return li
+    for _ in range(3):
+        step()
+    f8 = m.engine.fp8
+    pre = "encode_text.transformer.resblocks.0."
+    name = pre + "mlp.c_fc.weight"
+    old8 = f8.w8(pre, "fc_w").clone()
+    old_master = m.engine.arena.views[name].clone()
+    torch.manual_seed(123)
+    m.reset_text_encoder(1)
+    assert not torch.equal(m.engine.arena.views[name], old_master)
+    li = step()
+    assert bool(torch.isfinite(li).all())
+    scale = float(f8.scale[f8.slots[pre + "fc_w"]])
+    w = m.engine.arena.views[name].detach().cpu()
+    # the optimizer has not stepped: the masters are the reset values; their e4m3 image at the current scale
+    want = to_f8(w, scale, False).view(torch.uint8)
+    got = f8.w8(pre, "fc_w").cpu()
+    assert not torch.equal(got, old8.cpu())
+    assert not bool(((got != want) & ((got & 0x7f) != 0)).any()), "fp8 weight copy is not the quantised NEW weight"
+    got_t = f8.w8(pre, "fc_w", transposed=True).cpu()
+    assert torch.equal(got_t, got.t().contiguous())
+
+
+def test_fp8_state_is_not_advanced_by_inference_forwards():
+    """advisor finding (round 2): a no-grad forward (eval entry points; the data-parallel wrapper's prepare()) consumed the
+    observe-only step, so the first training step quantised e5m2 gradients at scale 1.  Only training forwards advance the
+    delayed-scaling state, fp8 GEMMs switch on after one observed forward AND backward, and a backward runs in the mode of
+    its own forward."""
+    from detfill import det_images, det_tokens
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    m, c = _tiny("fp8")
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 5)).cuda()
+    tok, mask = det_tokens(c["batch"], c["ctx"], 5)
+    texts = (torch.from_numpy(tok), torch.from_numpy(mask))
+    m.engine.prepare()                                   # what NativeDDP.__init__ does
+    with torch.no_grad():
+        m.encode_image(img)
+        m(img, texts)
+    f8 = m.engine.fp8
+    assert f8.steps == 0 and not f8.active and f8.bwd_seen == 0
+    wslot = f8.slots["visual.transformer.resblocks.0.fc_w"]
+    assert float(f8.scale[wslot]) != 1.0                 # ... but the weights are quantised with a real scale already
+    (li, lt), _ = m(img, texts)                          # training forward 1: observe only
+    assert f8.steps == 1 and not f8.active
+    (li2, lt2), _ = m(img, texts)                        # a second forward BEFORE any backward: still observe only
+    assert f8.steps == 2 and not f8.active
+    loss, _ = ClipInfoCELoss()(li2, lt2)
+    m.zero_grad()
+    loss.backward()
+    assert f8.bwd_seen == 1
+    (li3, lt3), _ = m(img, texts)                        # forward + backward observed: fp8 GEMMs from here on
+    assert f8.active
+    gslot = f8.slots["visual.transformer.resblocks.0.dout"]
+    assert float(f8.scale[gslot]) != 1.0, "gradient slots must have a history before fp8 GEMMs switch on"
+    # backward of the observe-only forward (li, lt) AFTER the state switched to active: runs in its own forward's mode
+    loss_old, _ = ClipInfoCELoss()(li, lt)
+    m.zero_grad()
+    loss_old.backward()
+    torch.cuda.synchronize()
+    g_old = m.visual.transformer.resblocks[0].mlp.c_fc.weight.grad.clone()
+    assert f8.active and bool(torch.isfinite(g_old).all())
+    mb, _ = _tiny("bf16")
+    (lb, ltb), _ = mb(img, texts)
+    lossb, _ = ClipInfoCELoss()(lb, ltb)
+    mb.zero_grad()
+    lossb.backward()
+    torch.cuda.synchronize()
+    gb = mb.visual.transformer.resblocks[0].mlp.c_fc.weight.grad
+    # (split-K fp32 atomics: equal up to the summation order)
+    assert float((g_old - gb).abs().max()) <= 1e-3 * float(gb.abs().max()), "observe-mode backward must equal the bf16 one"
 
 
 def test_fp8_loss_curve_tracks_bf16_at_real_size():
@@ -326,14 +493,15 @@ def test_fused_fp8_copies_equal_the_separate_quantise_pass():
     assert torch.equal(dx8b, dx8) and torch.equal(dxb, dx) and float(a2b) == float(a2)
 
 
-@pytest.mark.parametrize("packed", [False, True])
-def test_attention_kernels_emit_the_fp8_copy_of_their_output(packed):
+@pytest.mark.parametrize("packed,Lx", [(False, 50), (True, 50), (False, 257)])
+def test_attention_kernels_emit_the_fp8_copy_of_their_output(packed, Lx):
     """fp8 mode: attention forward / backward write the e4m3 copy of `out` / the e5m2 copy of `dqkv` themselves: the same
-    bytes and amax as a quantise pass over the bf16 tensor; the backward may drop the bf16 tensor altogether"""
+    bytes and amax as a quantise pass over the bf16 tensor; the backward may drop the bf16 tensor altogether.  L = 257 is
+    ViT-L/14's token count: the key-block backward kernel (round 3: no separate quantise pass for long sequences either)"""
     from ilvlm_amd import ops, lib as L
     h = L.load()
     st = torch.cuda.current_stream().cuda_stream
-    B, Lx, H = 5, 50, 4
+    B, H = 5, 4
     E = 64 * H
     if packed:
         lens = [50, 7, 33, 1, 16]

@@ -611,20 +611,20 @@ def test_weight_gradient_gemm_with_ragged_reduction(K):
     assert rel(bias, a.float().sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [5, 15])
+@pytest.mark.parametrize("variant", [5, 16])
 @pytest.mark.parametrize("M,N,K,tb", [(19712, 2048, 512, 0), (12800, 3072, 768, 0), (12800, 768, 3072, 1), (11319, 1536, 512, 0)])
 def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, tb):
     """Chip-filling launches of the step's shapes, repeated: every launch must reproduce the first bit for bit (no atomics in
     these kernels) and match an fp32 reference.  Guards the LDS race fixed at ILVLM_WG_BARRIER (csrc/gemm.hip): fragment reads
     still queued at the end-of-K-tile barrier were overtaken by the next tile's DMA in about one launch out of ten -- only at
-    sizes where four workgroups per CU keep the LDS pipeline busy, never at unit-test sizes.  Variant 15 runs the streaming
+    sizes where four workgroups per CU keep the LDS pipeline busy, never at unit-test sizes.  Variant 16 runs the streaming
     kernel (packed B operand, hand-placed waits around inline-asm loads): same guard for its two-stage ring, and its result
     must equal the direct-to-LDS kernel's bit for bit (same MFMA sequence per output element)."""
     ops = _ops()
     a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
     w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
     ref = a.float() @ (w.float() if tb else w.float().t())
-    wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant == 15 else None
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant == 16 else None
     try:
         ops.gemm_set_variant(5)
         base = torch.empty(M, N, device="cuda", dtype=torch.float32)
@@ -716,8 +716,9 @@ def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, monkeypatch):
         outs.append(outd)
         return outs
 
-    got = run(wp)
     try:
+        ops.gemm_set_variant(16)         # the streaming kernel for every eligible shape (15 keeps short K-loops on the other kernel)
+        got = run(wp)
         ops.gemm_set_variant(5)
         base = run(None)
     finally:

@@ -197,6 +197,13 @@ def _check_real_size(tag, model, p, o, loss_ref, li, lt, loss, emb, grad_sample)
               tag, e_li, e_lt, e_loss, e_img, e_txt, e_spread, min(coss.values()), min(coss, key=coss.get),
               min(mags.values()), max(mags.values())))
     assert e_li < 1e-2 and e_lt < 1e-2 and e_loss < 1e-2 and e_img < 1e-2 and e_txt < 1e-2
+    # what distinguishes the pairs: the logit error against the SPREAD of the logits (measured 5.7e-2 ViT-B/32 B=256,
+    # 4.9e-2 ViT-L/14 B=8), and against each row's own centred logits (the part the softmax of the loss sees)
+    assert e_spread < 0.1, "max logit error / logit spread %.3e" % e_spread
+    ref_c = o["logits_i"].detach() - o["logits_i"].detach().mean(1, keepdim=True)
+    got_c = li.detach().float().cpu() - li.detach().float().cpu().mean(1, keepdim=True)
+    e_centred = float((got_c - ref_c).abs().max()) / max(float(ref_c.abs().max()), 1e-30)
+    assert e_centred < 0.1, "row-centred logit error %.3e" % e_centred
     for n in grad_sample:
         assert coss[n] > 0.98, "bf16 gradient direction of %s: cos %.4f" % (n, coss[n])
         assert 0.9 < mags[n] < 1.1, "bf16 gradient norm of %s: ratio %.3f" % (n, mags[n])

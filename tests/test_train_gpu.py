@@ -340,6 +340,82 @@ def test_shadow_cast_is_skipped_only_when_the_optimizer_kept_it_current():
         ops.cast_f32 = real
 
 
+def test_codebook_pin_of_the_smooth_phase_reaches_the_bf16_forward():
+    """solver.keep_codebook_value() (reference train_solver.py:214,553) restores the codebook through `.data` right after an
+    optimizer step that wrote the bf16 shadow of the UPDATED codebook: the next forward must read the pinned values (advisor
+    finding, round 2: the trusted shadow kept the post-step codebook)."""
+    from ilvlm_amd import solver as S
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    from ilvlm_amd.prototype.optimizer import optim_entry
+    from ilvlm_amd.prototype.utils.misc import param_group_all
+    c, v = CFG["a"], FDT_VARIANTS[0]
+    kw = model_kwargs(c, v)
+    kw["precision"] = "bf16"
+    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=kw))
+    model.load_state_dict({k: torch.from_numpy(a) for k, a in det_state(state_shapes(c, True), 11).items()})
+    model.cuda().train()
+    opt = optim_entry(dict(type="AdamW", kwargs=dict(params=param_group_all(model, PCONFIG)[0], lr=1e-2, weight_decay=0.1,
+                                                     betas=[0.9, 0.98], amsgrad=False, eps=1e-8)))
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 5)).cuda()
+    tok, mask = det_tokens(c["batch"], c["ctx"], 5)
+    texts = (torch.from_numpy(tok), torch.from_numpy(mask))
+
+    class Holder:                                   # the two solver methods only touch self.model.module / self.stored_codebook
+        pass
+    h = Holder()
+    h.model = type("W", (), {"module": model})()
+    S.ClsSolver.store_codebook_value(h)
+    (li, lt), _ = model(img, texts)
+    opt.zero_grad()
+    ClipInfoCELoss()(li, lt)[0].backward()
+    opt.step()                                      # moves the codebook and writes its bf16 shadow
+    a = model.engine.arena
+    assert not torch.equal(model.space_dict.data, h.stored_codebook)
+    S.ClsSolver.keep_codebook_value(h)
+    assert torch.equal(model.space_dict.data, h.stored_codebook)
+    model(img, texts)
+    assert torch.equal(a.sviews["space_dict"], h.stored_codebook.to(torch.bfloat16)), "forward read the un-pinned codebook"
+    assert torch.equal(a.S, a.P.to(torch.bfloat16))
+
+
+def test_launch_stream_override_is_thread_local():
+    """ops.stream_override routes the launches of ITS thread only: a kernel launched from another thread (the prefetcher
+    normalising a uint8 batch) while the main thread sits inside an override must go to that thread's own current stream
+    (advisor finding, round 2: a module-global switch sent it to the weight-gradient stream, un-ordered against its copy)."""
+    import threading
+    from ilvlm_amd import ops
+    side = torch.cuda.Stream()
+    worker_stream = torch.cuda.Stream()
+    seen = {}
+    inside, go = threading.Event(), threading.Event()
+
+    def worker():
+        inside.wait(10)
+        with torch.cuda.stream(worker_stream):
+            seen["worker"] = ops._stream()
+            src = torch.randint(0, 255, (2, 8, 8, 3), dtype=torch.uint8, device="cuda")
+            seen["out"] = ops.image_u8_normalize(src)
+            seen["src"] = src
+        go.set()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    with ops.stream_override(side.cuda_stream):
+        assert ops._stream() == side.cuda_stream
+        inside.set()
+        assert go.wait(30)
+        assert ops._stream() == side.cuda_stream
+    t.join()
+    assert ops._stream() == torch.cuda.current_stream().cuda_stream
+    assert seen["worker"] == worker_stream.cuda_stream
+    worker_stream.synchronize()
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 3, 1, 1)
+    want = (seen["src"].cpu().permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    assert float((seen["out"].cpu() - want).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_adamw_issued_from_inside_backward_is_bit_identical(precision):
     """optimizer.overlap_backward(): every transformer block is updated on the optimizer's stream as soon as its gradients are
