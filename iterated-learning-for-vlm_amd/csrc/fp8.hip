@@ -71,19 +71,23 @@ __global__ __launch_bounds__(256) void fp8_weight_kernel(const float* __restrict
 }
 
 // delayed scaling: hist[slot][pos] = amax_cur[slot]; scale = fmt_max / max(hist) (1 while nothing was seen).  amax_cur
-// restarts at 0.9 x that maximum instead of 0: every wave of every quantising kernel compares its local maximum with
-// amax_cur and raises it atomically when larger -- from 0 the whole first generation of waves (thousands) would hit the one
-// word (12800 atomics at ~12 ns each made the fused LayerNorm 7x slower); from 0.9 max only genuine new maxima do.  The
-// recorded amax can therefore fall by at most 10 % per step, which only makes the scale more conservative.
+// restarts at 0.9 x the value just recorded instead of 0: every wave of every quantising kernel compares its local maximum
+// with amax_cur and raises it atomically when larger -- from 0 the whole first generation of waves (thousands) would hit the
+// one word (12800 atomics at ~12 ns each made the fused LayerNorm 7x slower); from 0.9 x the last step's amax only genuine
+// new maxima do.  A recorded amax can therefore fall by at most 10 % per step: after an outlier (one step at 100 x) the
+// entries decay geometrically and the scale is back within a few per cent in HIST + ~45 steps.  (Round 2 restarted at 0.9 x
+// the WINDOW maximum: the outlier then stayed the window maximum for HIST steps at a time and the decay was 10 % per HIST
+// steps, ~700 steps at a 100 x too conservative scale -- found by tests/test_fp8_gpu.py's amax-jump test.)
 __global__ __launch_bounds__(256) void fp8_scale_kernel(float* __restrict__ amax_cur, float* __restrict__ hist,
                                                         float* __restrict__ scale, float* __restrict__ inv_scale,
                                                         const float* __restrict__ fmt_max, int n, int hist_len, int pos) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    hist[(long)i * hist_len + pos] = amax_cur[i];
+    const float last = amax_cur[i];
+    hist[(long)i * hist_len + pos] = last;
     float m = 0.f;
     for (int k = 0; k < hist_len; ++k) m = fmaxf(m, hist[(long)i * hist_len + k]);
-    amax_cur[i] = (m > 0.f && isfinite(m)) ? 0.9f * m : 0.f;
+    amax_cur[i] = (last > 0.f && isfinite(last)) ? 0.9f * last : 0.f;
     const float s = (m > 0.f && isfinite(m)) ? fmt_max[i] / m : 1.f;
     scale[i] = s;
     inv_scale[i] = 1.f / s;
