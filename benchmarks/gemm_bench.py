@@ -17,9 +17,11 @@ SHAPES.append(("fdt.img.scores", 0, 0, 12544, 4096, 512, False, 1))
 SHAPES.append(("fdt.txt.scores", 0, 0, 19712, 4096, 512, False, 1))
 
 
-def run(rounds=7, only=None, epi=False):
+def run(rounds=7, only=None, epi=False, sk=True):
     torch.manual_seed(0)
     flush = torch.empty(128 * 1024 * 1024, device="cuda")
+    # slab workspace for the store-type split-K of the streaming kernel (what the engine offers per stream)
+    slab = (torch.empty(160 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(8192, dtype=torch.int32, device="cuda")) if sk else None
     tot = {5: 0.0, 15: 0.0}
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:
         if only and only not in tag:
@@ -40,7 +42,7 @@ def run(rounds=7, only=None, epi=False):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split,
-                         b_packed=packed if v == 15 else None, **kw)
+                         b_packed=packed if v == 15 else None, slab=slab if (v == 15 and not acc) else None, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
@@ -57,4 +59,4 @@ def run(rounds=7, only=None, epi=False):
 
 if __name__ == "__main__":
     args = [x for x in sys.argv[1:] if not x.startswith("--")]
-    run(only=args[0] if args else None, epi="--epi" in sys.argv)
+    run(only=args[0] if args else None, epi="--epi" in sys.argv, sk="--no-sk" not in sys.argv)

@@ -19,11 +19,14 @@ for (tag, ta, tb, M, N, K, acc, split, v, bm, bn, nw) in CASES:
     b = torch.randn((K, N) if tb else (N, K), device="cuda").to(torch.bfloat16)
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else torch.bfloat16)
     ops.gemm_set_variant(v)
-    packed = ops.gemm_pack_b(b, trans_b=bool(tb)) if v == 15 else None
+    packed = ops.gemm_pack_b(b, trans_b=bool(tb)) if (v == 15 and not acc) else None
+    slab = None
+    if os.environ.get("STAMP_SK") and v == 15 and not acc:
+        slab = (torch.empty(160 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(8192, dtype=torch.int32, device="cuda"))
     flush = torch.empty(128 * 1024 * 1024, device="cuda")
     for _ in range(3):
         flush.zero_()
-        ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split, b_packed=packed)
+        ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split, b_packed=packed, slab=slab)
     torch.cuda.synchronize()
     nb = min(4096, ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * split)
     print(tag)

@@ -1158,9 +1158,11 @@ __device__ __forceinline__ void pk_load_b1(bf16x8& b, pk_i32x4 rs, int voff, int
 template <int NP>
 __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane,
                                               bf16x8 (&bn)[4][2], pk_i32x4 rsa, int a_voff, int a_soff, int a_jstep, unsigned lds,
-                                              pk_i32x4 rsb, int b_voff, int s0, int s1, int s2, int s3, int ok) {
+                                              pk_i32x4 rsb, int b_voff, int s0, int s1, int s2, int s3, int ok_b, int ok_a) {
     // the A fragment of group g + 1 is requested before the MFMAs of group g (the load statements between them are volatile
-    // asm: the compiler keeps their order, so it cannot hoist the reads itself)
+    // asm: the compiler keeps their order, so it cannot hoist the reads itself).  Issue order = wait order: the eight B
+    // loads of K-tile t + 1 first (needed at the top of the next step), then the A pieces of K-tile t + 2, which the next
+    // step's counted vmcnt leaves in flight.
     bf16x8 fa = p8_frag<false, 128, 64>(as, 0, 0, lane);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -1168,12 +1170,12 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned
         bf16x8 fn = fa;
         if (g + 1 < 16) fn = p8_frag<false, 128, 64>(as, ((g + 1) & 7) * 16, ((g + 1) >> 3) * 32, lane);
         __builtin_amdgcn_sched_barrier(0);          // keeps the read above this group's MFMAs (hipcc sinks it to reuse the register)
-        if (g < NP) pk_dma1(rsa, a_voff, a_soff + g * a_jstep, lds + g * 1024, ok);
-        else if (g < NP + 8) {
-            const int q = g - NP;                       // B load q: column tile q >> 1, k-step q & 1
-            const int so = (q >> 1) == 0 ? s0 : (q >> 1) == 1 ? s1 : (q >> 1) == 2 ? s2 : s3;
-            if (q & 1) pk_load_b1<1024>(bn[q >> 1][1], rsb, b_voff, so, ok);
-            else pk_load_b1<0>(bn[q >> 1][0], rsb, b_voff, so, ok);
+        if (g < 8) {
+            const int so = (g >> 1) == 0 ? s0 : (g >> 1) == 1 ? s1 : (g >> 1) == 2 ? s2 : s3;    // column tile g >> 1, k-step g & 1
+            if (g & 1) pk_load_b1<1024>(bn[g >> 1][1], rsb, b_voff, so, ok_b);
+            else pk_load_b1<0>(bn[g >> 1][0], rsb, b_voff, so, ok_b);
+        } else if (g < 8 + NP) {
+            pk_dma1(rsa, a_voff, a_soff + (g - 8) * a_jstep, lds + (g - 8) * 1024, ok_a);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], fa, acc[i][j], 0, 0, 0);
@@ -1195,16 +1197,22 @@ __device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned ch
 }
 #endif
 
-template <int WN, bool IL>
+// STG = 3 (default): three A stages, prefetch distance 2 for A and 1 for B, loads interleaved with the MFMAs.  STG = 2: two
+// stages, everything one K-tile ahead, loads issued as a block in front of the MFMAs (the first form; kept as the A/B).
+template <int WN, int STG>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
-                                                                  int K, int tiles_m, int tiles_n, EpiArgs ep) {
+                                                                  int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
     constexpr int STAGE = 128 * 64 * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // the K-slices of a tile are neighbours in the linear order: they run at the same time, on the same XCD
+    int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n * split_k);
+    const int zs = wg % split_k;
+    wg /= split_k;
+    const int tile_id = wg;
     int tn = wg % tiles_n, tm = wg / tiles_n;
     if (ep.tile_group > 0) {            // L2 blocking of the tile walk, as in gemm_bf16_dma_kernel
         const int idx = wg, Hb = (tiles_m + ep.tile_bands - 1) / ep.tile_bands, G = ep.tile_group;
@@ -1217,7 +1225,9 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         tn = g * G + rr % gw;
     }
     const int m0 = tm * 128, n0 = tn * (64 * WN);
-    const int nt = K >> 6;
+    // this workgroup's K-tiles [t0, t0 + nt): an equal share (the host makes split_k divide into non-empty slices)
+    const int nt_all = K >> 6, per = (nt_all + split_k - 1) / split_k;
+    const int t0 = zs * per, nt = min(per, nt_all - t0);
 
     // A: per-lane source offset of piece 0 (rows 8 (wave NP) + (lane >> 3), 16-byte chunk (lane & 7) ^ (row & 7)); pieces
     // step 8 rows, which leaves the swizzle unchanged
@@ -1225,13 +1235,13 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
     const int arow = wave * NP * 8 + (lane >> 3);
     const int a_voff = (arow * lda + (((lane & 7) ^ (arow & 7)) << 3)) * 2;
     const int a_jstep = 8 * lda * 2;
-    int a_soff = m0 * lda * 2;                                       // + 128 bytes per K-tile
+    int a_soff = m0 * lda * 2 + t0 * 128;                            // + 128 bytes per K-tile
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_raw + wave * NP * 1024;
     // B: this wave's 4 column tiles of 16; block (n / 16, k / 32) is KiB number (n / 16) * (K / 32) + k / 32
     const pk_i32x4 rsb = pk_rsrc(Bp, (long)ep.N * K * 2);
     const int b_voff = lane * 16;
     const int kb = (K >> 5) << 10;                                   // bytes per column tile
-    int bs0 = ((n0 >> 4) + wave * 4) * kb, bs1 = bs0 + kb, bs2 = bs1 + kb, bs3 = bs2 + kb;     // + 2 KiB per K-tile
+    int bs0 = ((n0 >> 4) + wave * 4) * kb + t0 * 2048, bs1 = bs0 + kb, bs2 = bs1 + kb, bs3 = bs2 + kb;     // + 2 KiB per K-tile
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -1240,8 +1250,6 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
     bf16x8 b0[4][2], b1[4][2];
 
-    // one K-tile: wait for what was issued a step ago, barrier, prefetch the next K-tile (skipped inside the asm when there
-    // is none), multiply.  Straight-line code on purpose (see pk_dma).
 #ifdef ILVLM_GEMM_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
     STAMP(t_start);
@@ -1249,6 +1257,53 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
 #else
 #define PK_KEEP()
 #endif
+    if constexpr (STG == 3) {
+        // Prefetch distance 2 for A.  In-kernel stamps of the two-stage form: with the loads interleaved into the MFMA
+        // stream a wave waited 1267 cycles per K-step at vmcnt (37 % of the loop) -- the last loads of a step are issued too
+        // late to land by the next, and the A operand is a cold HBM stream (each row block is read once per launch).  So A
+        // gets a third stage: step t multiplies stage t % 3 while A(t+1) is already in flight or landed and A(t+2) is
+        // being issued.  B stays one K-tile ahead in its second register set (weights: L2 / Infinity-Cache resident) and
+        // is issued in the FIRST half of the step.
+        //   step t:  vmcnt(NP)  [all but the NP youngest = the pieces of A(t+1); vmcnt(0) on the last step]; barrier
+        //            groups 0-7: B(t+1) -> other register set      groups 8..: A(t+2) -> stage (t+2) % 3
+        //   RAW: a wave's own A(t) pieces were retired by the vmcnt of step t-1 or t, everyone else's by a barrier behind
+        //        it.  WAR: stage (t+2) % 3 = (t-1) % 3 was last read in step t-1; its refill is issued behind the barrier
+        //        of step t, which every wave passes after those reads returned (lgkmcnt(0) in front of the barrier).
+        int st_cur = 0;                                       // stage of K-tile t
+#define PK_STEP3(BCUR, BNXT, T)                                                                         \
+    do {                                                                                                \
+        const int more1 = __builtin_amdgcn_readfirstlane((T) + 1 < nt ? 1 : 0);                         \
+        const int more2 = __builtin_amdgcn_readfirstlane((T) + 2 < nt ? 1 : 0);                         \
+        STAMP(p0);                                                                                      \
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpk_w0%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lpk_w1%=\n\t" \
+                     ".Lpk_w0%=:\n\ts_waitcnt vmcnt(0)\n\t.Lpk_w1%=:" ::"s"(more1), "n"(NP) : "memory", "scc");             \
+        pk_landed(BCUR);                                                                                \
+        STAMP(p1);                                                                                      \
+        ILVLM_WG_BARRIER();                                                                             \
+        STAMP(p2);                                                                                      \
+        a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;                             \
+        const int st_nn = st_cur == 0 ? 2 : st_cur - 1;       /* (st_cur + 2) % 3 */                    \
+        pk_compute_il<NP>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep,        \
+                          lds0 + st_nn * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, more1, more2);         \
+        PK_KEEP();                                                                                      \
+        st_cur = st_cur == 2 ? 0 : st_cur + 1;                                                          \
+        STAMP(p4);                                                                                      \
+        STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_comp, p2, p4);                 \
+    } while (0)
+        // prologue in wait order: A(0), B(0), then A(1) (which the first step's counted vmcnt leaves in flight)
+        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
+        pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
+        pk_dma<NP>(rsa, a_voff, a_soff + 128, a_jstep, lds0 + STAGE, __builtin_amdgcn_readfirstlane(nt > 1 ? 1 : 0));
+        const int pairs = nt >> 1;
+        for (int tp = 0; tp < pairs; ++tp) {
+            PK_STEP3(b0, b1, 2 * tp);
+            PK_STEP3(b1, b0, 2 * tp + 1);
+        }
+        if (nt & 1) PK_STEP3(b0, b1, nt - 1);
+#undef PK_STEP3
+    } else {
+        // one K-tile: wait for what was issued a step ago, barrier, prefetch the next K-tile (skipped inside the asm when
+        // there is none), multiply.  Straight-line code on purpose (see pk_dma).
 #define PK_STEP(CUR_STAGE, NXT_STAGE, BCUR, BNXT, MORE)                                   \
     do {                                                                                  \
         STAMP(p0);                                                                        \
@@ -1258,15 +1313,6 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         ILVLM_WG_BARRIER();                                                               \
         STAMP(p2);                                                                        \
         a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;               \
-        if constexpr (IL) {                                                               \
-            STAMP(p3);                                                                    \
-            pk_compute_il<NP>(acc, smem_raw + (CUR_STAGE) * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff, a_jstep,   \
-                              lds0 + (NXT_STAGE) * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                    \
-            PK_KEEP();                                                                    \
-            STAMP(p4);                                                                    \
-            STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_issue, p2, p3); STAMP_ADD(c_comp, p3, p4); \
-            break;                                                                        \
-        }                                                                                 \
         pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0 + (NXT_STAGE) * STAGE, MORE);       \
         pk_load_b(BNXT, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                           \
         STAMP(p3);                                                                        \
@@ -1275,15 +1321,16 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         STAMP(p4);                                                                        \
         STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_issue, p2, p3); STAMP_ADD(c_comp, p3, p4); \
     } while (0)
-    pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
-    pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
-    const int pairs = nt >> 1;
-    for (int tp = 0; tp < pairs; ++tp) {
-        PK_STEP(0, 1, b0, b1, 1);
-        PK_STEP(1, 0, b1, b0, __builtin_amdgcn_readfirstlane(2 * tp + 2 < nt ? 1 : 0));
-    }
-    if (nt & 1) PK_STEP(0, 1, b0, b1, 0);
+        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
+        pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
+        const int pairs = nt >> 1;
+        for (int tp = 0; tp < pairs; ++tp) {
+            PK_STEP(0, 1, b0, b1, 1);
+            PK_STEP(1, 0, b1, b0, __builtin_amdgcn_readfirstlane(2 * tp + 2 < nt ? 1 : 0));
+        }
+        if (nt & 1) PK_STEP(0, 1, b0, b1, 0);
 #undef PK_STEP
+    }
 #undef PK_KEEP
 #ifdef ILVLM_GEMM_STAMPS
     STAMP(t_loop_end);
@@ -1294,6 +1341,91 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
     if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
     // every wave is done reading the operand stages before any wave transposes its fragments through the same LDS
     __syncthreads();
+    if (split_k > 1) {
+        // Store-type split-K (round 3).  The deep-K / narrow-N products of the step (down-projection forward, up- and
+        // in-projection input gradients: 600 / 356 tiles of 128x128 for 1024 slots, 24...48 K-tiles each) leave about ONE
+        // wave per SIMD, so every wave's issue -> multiply -> wait chain is exposed (36 % MFMA duty in the in-kernel
+        // stamps).  Splitting K doubles the waves in flight and halves the chain.  Hand-off without a scheduling
+        // dependency and without atomics on C: a workgroup that finishes its K-slice draws a ticket; all but the last
+        // arriver PUBLISH their partial tile (fp32 fragments, write-through stores, then a counter); the last arriver
+        // waits for the publishers -- all of them are past their K-loop already, whatever the dispatch order --, adds the
+        // slabs IN SLICE ORDER (its own registers in their place: the sum does not depend on who arrived when, results are
+        // bit-reproducible) and alone runs the epilogue.  Protocol: cdna_hip_programming.md guideline 16 R1 (sc1 stores,
+        // every storing wave drains vmcnt, barrier, relaxed agent-scope counter; the consumer polls relaxed and reads with
+        // sc1 loads only).  cnt[tile] = tickets, cnt[ntiles + tile] = published slabs; the last arriver zeroes both.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int SLAB = 128 * 64 * WN * 4;
+        const int ntiles = tiles_m * tiles_n;
+        __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(ep.e.splitk_ws, 0, ntiles * split_k * SLAB, 0x00020000);
+        const int slab0 = tile_id * split_k * SLAB;
+        int* cnt = ep.e.splitk_cnt;
+        if (tid == 0) *(volatile int*)smem_raw = __hip_atomic_fetch_add(cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *(volatile int*)smem_raw;
+        __syncthreads();                         // wave 0's transpose slice starts at that word
+        if (ticket != split_k - 1) {
+            const int mine = slab0 + zs * SLAB + wave * (8 * 4 * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { f32x4 f; u32x4 u; } x;
+                    x.f = acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(x.u, ws, mine + (i * 4 + j) * 1024 + lane * 16, 0, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + ntiles + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            while (__hip_atomic_load(cnt + ntiles + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_k - 1)
+                __builtin_amdgcn_s_sleep(4);
+            __hip_atomic_store(cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // next launch
+            __hip_atomic_store(cnt + ntiles + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // compiler ordering only: the loads stay below the poll
+        if (split_k == 2) {                       // a + b == b + a: one slab to add, no order to keep
+            const int sl = slab0 + (1 - zs) * SLAB + wave * (8 * 4 * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { f32x4 f; u32x4 u; } x;
+                    x.u = __builtin_amdgcn_raw_buffer_load_b128(ws, sl + (i * 4 + j) * 1024 + lane * 16, 0, 16);
+                    acc[i][j] += x.f;
+                    if (j == 3 && (i & 1)) asm volatile("" ::: "memory");      // at most 8 loads in flight: 32 would spill
+                }
+        } else {
+            // three or more slices: the sum must not depend on which slice arrived last.  The last arriver parks its own
+            // fragments in its slab too (each wave re-reads only what it wrote itself) and adds ALL slabs in slice order
+            // -- no second register set for the 128 accumulators.
+            const int mine = slab0 + zs * SLAB + wave * (8 * 4 * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { f32x4 f; u32x4 u; } x;
+                    x.f = acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(x.u, ws, mine + (i * 4 + j) * 1024 + lane * 16, 0, 16);
+                    acc[i][j] = (f32x4){0, 0, 0, 0};
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int z = 0; z < split_k; ++z) {
+                const int sl = slab0 + z * SLAB + wave * (8 * 4 * 1024);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        union { f32x4 f; u32x4 u; } x;
+                        x.u = __builtin_amdgcn_raw_buffer_load_b128(ws, sl + (i * 4 + j) * 1024 + lane * 16, 0, 16);
+                        acc[i][j] += x.f;
+                        if (j == 3 && (i & 1)) asm volatile("" ::: "memory");
+                    }
+            }
+        }
+    }
     epilogue_tile<8, 4>(ep, acc, m0, n0 + wave * 64, lane, alpha, smem_raw + wave * 8192);
 #ifdef ILVLM_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1478,13 +1610,13 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <int WN, bool IL>
-int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_pk_kernel<WN, IL>;
-    constexpr int ring = 2 * 128 * 64 * 2, epi = WN * 8192;
+template <int WN, int STG>
+int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    auto kern = gemm_bf16_pk_kernel<WN, STG>;
+    constexpr int ring = STG * 128 * 64 * 2, epi = WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
-    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, ep);
+    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, split_k, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
     return ILVLM_OK;
 }
@@ -1506,6 +1638,8 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 //   15 (default) = the streaming kernel (weights pre-packed in fragment order, gemm_bf16_pk_kernel) wherever the caller
 //                  offers a packed copy of B, the direct-to-LDS 128x128 kernel everywhere else;
 //   16           = as 15, but the streaming kernel for EVERY eligible shape with a packed B (tests: short K-loops);
+//   17           = as 16, plus store-type split-K (2..4 slices) wherever the caller offers a slab workspace (tests; opt-in
+//                  for production through ILVLM_PK_SPLITK -- measured slower on the step's shapes);
 //    5           = always the single-stage direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
 //    0           = the register-staged general kernel only.
 // The tilings and pipelines that rounds 1 and 2 measured and lost with (64x128, 256x128 3-stage, 256x256 phased, stream-K,
@@ -1625,17 +1759,39 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // ViT-B/32 shapes with 128x256 tiles) and loses 7..12 % on the K = 512 shapes of the text tower (8 K-tiles), which
         // keep the direct-to-LDS kernel.
         static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 768;
-        if ((variant == 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
+        if ((variant >= 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
             (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
             static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 4;
             const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
             const int tn_pk = ceil_div(N, 64 * wn);
             ep.tile_group = (tile_group_env > 0 && K <= tile_kmax_env && tn_pk > tile_group_env) ? tile_group_env : 0;
-            static const int pk_il = getenv("ILVLM_PK_IL") ? atoi(getenv("ILVLM_PK_IL")) : 1;
-            if (wn == 4) return pk_il ? launch_pk<4, true>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s)
-                                      : launch_pk<4, false>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
-            return pk_il ? launch_pk<2, true>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s)
-                         : launch_pk<2, false>(a, lda, (const bf16*)epi->b_packed, K, M, N, ep, s);
+            static const int pk_stg = getenv("ILVLM_PK_STAGES") ? atoi(getenv("ILVLM_PK_STAGES")) : 3;
+            // store-type split-K: when the caller offers a slab workspace and the launch would leave the chip short of waves
+            // (tiles x waves below ~2 per SIMD) while the K-loop is long enough to cut (>= 6 K-tiles per slice)
+            int sk = 1;
+            // (measured SLOWER on every shape of the step -- the slab exchange costs ~20 us per tile pair and the extra waves
+            // only add contention: these shapes are load-latency bound, not wave-starved -- so it is opt-in:
+            // ILVLM_PK_SPLITK=<max slices>; the tests force it.  DESIGN.md section 6.)
+            static const int pk_sk_max = getenv("ILVLM_PK_SPLITK") ? atoi(getenv("ILVLM_PK_SPLITK")) : 1;
+            static const int pk_sk_target = getenv("ILVLM_PK_SPLITK_WAVES") ? atoi(getenv("ILVLM_PK_SPLITK_WAVES")) : 2048;
+            const int sk_cap = variant == 17 ? 4 : pk_sk_max;
+            if (slab_ws && epi->splitk_cnt && sk_cap > 1 && !epi->pool_out) {
+                const long tiles = (long)ceil_div(M, 128) * tn_pk, nt_ = K / 64;
+                int want = (int)((pk_sk_target + tiles * wn - 1) / (tiles * wn));       // slices to reach the wave target
+                if (want > sk_cap) want = sk_cap;
+                while (want > 1 && nt_ / want < 6) --want;
+                while (want > 1 && (long)(want - 1) * ceil_div(nt_, want) >= nt_) --want;           // every slice non-empty
+                const long slab = 128L * 64 * wn * 4;
+                if (want > 1 && 2 * tiles <= epi->splitk_cnt_len && tiles * want * slab <= epi->splitk_ws_bytes &&
+                    tiles * want * slab < (1L << 31)) {
+                    sk = want;
+                    ep.e.splitk_ws = slab_ws;
+                }
+            }
+            if (wn == 4) return pk_stg == 2 ? launch_pk<4, 2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s)
+                                            : launch_pk<4, 3>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
+            return pk_stg == 2 ? launch_pk<2, 2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s)
+                               : launch_pk<2, 3>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
         }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU
@@ -1681,7 +1837,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 15 || variant == 16, "gemm_set_variant: 0, 5, 15 or 16");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || (variant >= 15 && variant <= 17), "gemm_set_variant: 0, 5, 15, 16 or 17");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }

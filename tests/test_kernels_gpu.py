@@ -644,6 +644,49 @@ def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, 
         ops.gemm_set_variant(15)
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(12800, 768, 3072, 0), (12800, 768, 2304, 1), (11319, 512, 2048, 0), (11319, 512, 1536, 1),
+                                      (1000, 256, 768, 0), (300, 144, 1536, 1)])
+def test_streaming_gemm_store_type_split_k(M, N, K, tb):
+    """deep-K / narrow-N store-type products (down-projection forward, up- and in-projection input gradients) split K over
+    2-4 workgroups per tile when the caller offers a slab workspace: all but the last arriver publish their partial tile, the
+    last one adds the slabs in slice order and runs the epilogue (opt-in: measured slower than the unsplit kernel on the
+    step's shapes; selector 17 forces it here).  Equal to the fp32 reference through the bias / residual
+    epilogue, bit-identical from launch to launch (no atomics on C, a sum that does not depend on arrival order), counters left
+    at zero for the next launch, and the workspace untouched when none is offered."""
+    ops = _ops()
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb))
+    ref = a.float() @ (w.float() if tb else w.float().t())
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    want = ref + bias + res
+    slab = (torch.empty(160 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(8192, dtype=torch.int32, device="cuda"))
+    slab[0].fill_(0xff)                       # NaN patterns: a slab read before it was written would poison the result
+    try:
+        ops.gemm_set_variant(16)
+        base = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, base, trans_b=bool(tb), bias=bias, residual=res, b_packed=wp, slab=slab)     # 16: never splits
+        assert int((slab[0][:4096] != 0xff).sum()) == 0
+        ops.gemm_set_variant(17)                                                                     # 17: splits where offered
+        assert float((base - want).abs().max()) < 2e-5 * float(want.abs().max())
+        first = None
+        for it in range(8):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(a, w, out, trans_b=bool(tb), bias=bias, residual=res, b_packed=wp, slab=slab)
+            assert float((out - want).abs().max()) < 2e-5 * float(want.abs().max()), "launch %d" % it
+            if first is None:
+                first = out
+            else:
+                assert torch.equal(out, first), "launch %d differs from launch 0" % it
+        assert int(slab[1].abs().sum()) == 0
+        # the split really happened: slabs were written (no 0xff pattern left at the start of the workspace) ...
+        assert int((slab[0][:4096] != 0xff).sum()) > 0
+        # ... and changes the summation order: equal to the unsplit kernel to fp32 rounding, not bit for bit
+        assert float((first - base).abs().max()) < 1e-5 * float(want.abs().max())
+    finally:
+        ops.gemm_set_variant(15)
+
+
 def _unpack_b(packed, n, k):
     """inverse of the fragment order of ilvlm_gemm_pack_b (include/ilvlm_hip.h): [n, k] from the packed image"""
     p = packed.view(n // 16, k // 32, 4, 16, 8)           # block (n/16, k/32), lane = 16 * (l >> 4) + (l & 15), 8 elements
