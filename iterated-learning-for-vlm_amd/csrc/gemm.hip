@@ -1199,7 +1199,10 @@ __device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned ch
 
 // STG = 3 (default): three A stages, prefetch distance 2 for A and 1 for B, loads interleaved with the MFMAs.  STG = 2: two
 // stages, everything one K-tile ahead, loads issued as a block in front of the MFMAs (the first form; kept as the A/B).
-template <int WN, int STG>
+// SK: compiled with the store-type split-K hand-off (a separate instantiation: its slab reduction raises the register
+// allocation from ~200 to 256 per lane, which at two waves per SIMD would leave no room for a co-resident wave of another
+// kernel -- and the step runs four streams).
+template <int WN, int STG, bool SK>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
                                                                   int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1341,7 +1344,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
     if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
     // every wave is done reading the operand stages before any wave transposes its fragments through the same LDS
     __syncthreads();
-    if (split_k > 1) {
+    if constexpr (SK) if (split_k > 1) {
         // Store-type split-K (round 3).  The deep-K / narrow-N products of the step (down-projection forward, up- and
         // in-projection input gradients: 600 / 356 tiles of 128x128 for 1024 slots, 24...48 K-tiles each) leave about ONE
         // wave per SIMD, so every wave's issue -> multiply -> wait chain is exposed (36 % MFMA duty in the in-kernel
@@ -1612,11 +1615,14 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
 
 template <int WN, int STG>
 int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_pk_kernel<WN, STG>;
     constexpr int ring = STG * 128 * 64 * 2, epi = WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
-    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, split_k, ep);
+    if (split_k > 1)
+        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, STG, true>), dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn,
+                           split_k, ep);
+    else
+        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, STG, false>), dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, 1, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
     return ILVLM_OK;
 }
@@ -1758,7 +1764,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // streaming kernel wins where the K-loop is long enough to amortise its two-deep prologue (K >= 768: +5..11 % on the
         // ViT-B/32 shapes with 128x256 tiles) and loses 7..12 % on the K = 512 shapes of the text tower (8 K-tiles), which
         // keep the direct-to-LDS kernel.
-        static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 768;
+        static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 512;
         if ((variant >= 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
             (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
             static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 4;
