@@ -1060,15 +1060,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
 //     in the workgroup needs them, and the registers double-buffer B (K-tile t+1 lands while t is multiplied);
 //   * a wave owns 128 rows x 64 columns (8 x 4 accumulator tiles, 2 waves per SIMD): half the LDS fragment reads per
 //     FLOP of the 64 x 64 wave tiles; WN waves side by side: workgroup tile 128 x (64 WN);
-//   * every load of the main loop is inline asm and every wait is placed by hand (one `s_waitcnt vmcnt(0)` + ONE barrier per
-//     K-tile, both at the top of the step, when the loads waited for have had a whole compute phase to land):
-//         step t:  vmcnt(0); barrier            A(t) of every wave is in LDS, B(t) in registers; stage (t+1)&1 is free
-//                  issue A(t+1) -> stage (t+1)&1 ; issue B(t+1) -> the other register set
-//                  16 ds_read_b128 + 64 MFMA on stage t&1 and B(t)
-//     RAW: a wave's own pieces are retired by its vmcnt(0), everyone else's by the barrier behind it.  WAR: the DMA into
-//     stage (t+1)&1 is issued behind the barrier of step t, which every wave passes only after the last fragment read of
-//     step t-1 has returned (lgkmcnt(0) in front of the barrier).  B registers: VMEM writes them after the MFMAs that read
-//     them have issued (in-order issue).
+//   * every load of the main loop is inline asm and every wait is placed by hand: ONE counted `s_waitcnt vmcnt` + ONE barrier
+//     per K-tile, both at the top of the step; A runs two K-tiles ahead through a THREE-stage ring, B one K-tile ahead in its
+//     second register set, and the loads are issued one by one between the groups of four MFMAs (schedule, hazards and the
+//     measurements behind it: at the main loop below).  The first form of this kernel -- two stages, everything one K-tile
+//     ahead, the 16 loads issued as a block in front of the MFMAs -- is in the git history: 858 us against 801 us per
+//     ViT + text block pair of forward + input-gradient launches.
 // Same MFMA sequence per output element as the direct-to-LDS kernel: results are bit-identical.
 // =====================================================================================
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1183,26 +1180,12 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned
     }
 }
 
-// 64 MFMAs of one K-tile: A fragments from the LDS stage, B fragments from registers (C^T fragments as everywhere else:
-// a lane owns output row (l & 15) and 4 consecutive columns)
-__device__ __forceinline__ void pk_compute(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bf16x8 fa = p8_frag<false, 128, 64>(as, i * 16, ks * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], fa, acc[i][j], 0, 0, 0);
-        }
-}
 #endif
 
-// STG = 3 (default): three A stages, prefetch distance 2 for A and 1 for B, loads interleaved with the MFMAs.  STG = 2: two
-// stages, everything one K-tile ahead, loads issued as a block in front of the MFMAs (the first form; kept as the A/B).
 // SK: compiled with the store-type split-K hand-off (a separate instantiation: its slab reduction raises the register
 // allocation from ~200 to 256 per lane, which at two waves per SIMD would leave no room for a co-resident wave of another
 // kernel -- and the step runs four streams).
-template <int WN, int STG, bool SK>
+template <int WN, bool SK>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
                                                                   int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1260,7 +1243,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
 #else
 #define PK_KEEP()
 #endif
-    if constexpr (STG == 3) {
+    {
         // Prefetch distance 2 for A.  In-kernel stamps of the two-stage form: with the loads interleaved into the MFMA
         // stream a wave waited 1267 cycles per K-step at vmcnt (37 % of the loop) -- the last loads of a step are issued too
         // late to land by the next, and the A operand is a cold HBM stream (each row block is read once per launch).  So A
@@ -1304,35 +1287,6 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         }
         if (nt & 1) PK_STEP3(b0, b1, nt - 1);
 #undef PK_STEP3
-    } else {
-        // one K-tile: wait for what was issued a step ago, barrier, prefetch the next K-tile (skipped inside the asm when
-        // there is none), multiply.  Straight-line code on purpose (see pk_dma).
-#define PK_STEP(CUR_STAGE, NXT_STAGE, BCUR, BNXT, MORE)                                   \
-    do {                                                                                  \
-        STAMP(p0);                                                                        \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
-        pk_landed(BCUR);                                                                  \
-        STAMP(p1);                                                                        \
-        ILVLM_WG_BARRIER();                                                               \
-        STAMP(p2);                                                                        \
-        a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;               \
-        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0 + (NXT_STAGE) * STAGE, MORE);       \
-        pk_load_b(BNXT, rsb, b_voff, bs0, bs1, bs2, bs3, MORE);                           \
-        STAMP(p3);                                                                        \
-        pk_compute(acc, smem_raw + (CUR_STAGE) * STAGE, BCUR, lane);                      \
-        PK_KEEP();                                                                        \
-        STAMP(p4);                                                                        \
-        STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_issue, p2, p3); STAMP_ADD(c_comp, p3, p4); \
-    } while (0)
-        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
-        pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
-        const int pairs = nt >> 1;
-        for (int tp = 0; tp < pairs; ++tp) {
-            PK_STEP(0, 1, b0, b1, 1);
-            PK_STEP(1, 0, b1, b0, __builtin_amdgcn_readfirstlane(2 * tp + 2 < nt ? 1 : 0));
-        }
-        if (nt & 1) PK_STEP(0, 1, b0, b1, 0);
-#undef PK_STEP
     }
 #undef PK_KEEP
 #ifdef ILVLM_GEMM_STAMPS
@@ -1613,16 +1567,16 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <int WN, int STG>
+template <int WN>
 int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    constexpr int ring = STG * 128 * 64 * 2, epi = WN * 8192;
+    constexpr int ring = 3 * 128 * 64 * 2, epi = WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
     if (split_k > 1)
-        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, STG, true>), dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn,
+        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, true>), dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn,
                            split_k, ep);
     else
-        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, STG, false>), dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, 1, ep);
+        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, false>), dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, 1, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
     return ILVLM_OK;
 }
@@ -1771,7 +1725,6 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
             const int tn_pk = ceil_div(N, 64 * wn);
             ep.tile_group = (tile_group_env > 0 && K <= tile_kmax_env && tn_pk > tile_group_env) ? tile_group_env : 0;
-            static const int pk_stg = getenv("ILVLM_PK_STAGES") ? atoi(getenv("ILVLM_PK_STAGES")) : 3;
             // store-type split-K: when the caller offers a slab workspace and the launch would leave the chip short of waves
             // (tiles x waves below ~2 per SIMD) while the K-loop is long enough to cut (>= 6 K-tiles per slice)
             int sk = 1;
@@ -1794,10 +1747,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                     ep.e.splitk_ws = slab_ws;
                 }
             }
-            if (wn == 4) return pk_stg == 2 ? launch_pk<4, 2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s)
-                                            : launch_pk<4, 3>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
-            return pk_stg == 2 ? launch_pk<2, 2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s)
-                               : launch_pk<2, 3>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
+            if (wn == 4) return launch_pk<4>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
+            return launch_pk<2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
         }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU

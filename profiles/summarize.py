@@ -63,14 +63,19 @@ def main():
                   "# so busy cycles are set against (GRBM_GUI_ACTIVE / 8) x 1024 SIMDs.  MFMA FLOPs = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512.",
                   "%-40s %10s %14s %10s" % ("kernel", "MfmaUtil %", "GFLOP/launch", "launches")]
         mout = {}
+        # effective clock (round 3): GRBM_GUI_ACTIVE / 8 XCDs / average launch duration of the same kernel in the serial
+        # kernel-stats pass (MI355X_MICROARCH.md, DVFS give-back: reads high on dispatches shorter than ~0.3 ms)
+        avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+        lines[-1] += " %12s" % "clock GHz"
         for k in sorted(agg, key=lambda k: -agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:8]:
             busy, gui = agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), agg[k].get("GRBM_GUI_ACTIVE", 0.0)
             if gui <= 0 or busy <= 0:
                 continue
             util = 100.0 * busy / (gui / 8.0 * 1024.0)
             gfl = agg[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / max(cnt[k], 1) / 1e9
-            mout[k] = dict(mfma_util_pct=util, mfma_gflop_per_launch=gfl, launches=cnt[k])
-            lines.append("%-40s %10.1f %14.2f %10d" % (k, util, gfl, cnt[k]))
+            clock = gui / 8.0 / max(cnt[k], 1) / avg_ns[k] if k in avg_ns else float("nan")
+            mout[k] = dict(mfma_util_pct=util, mfma_gflop_per_launch=gfl, launches=cnt[k], effective_clock_ghz=clock)
+            lines.append("%-40s %10.1f %14.2f %10d %12.2f" % (k, util, gfl, cnt[k], clock))
         json.dump(mout, open(os.path.join(a.dst, "mfma_util.json"), "w"), indent=1)
     traffic = {}
     for what in ("fetch", "write"):
@@ -101,6 +106,21 @@ def main():
                   % (tot_r / nsteps_pmc / 1e9, tot_w / nsteps_pmc / 1e9, nsteps_pmc)]
         out["_step_total"] = dict(read_gb=tot_r / nsteps_pmc / 1e9, write_gb=tot_w / nsteps_pmc / 1e9)
         json.dump(out, open(os.path.join(a.dst, "hbm_traffic.json"), "w"), indent=1)
+    tc = glob.glob(os.path.join(a.src, "tcc", "*", "*_counter_collection.csv"))
+    if tc:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(tc[0])):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        lines += ["", "# L2 (TCC) hit rate per kernel: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), all launches of the counter pass",
+                  "%-40s %10s %16s" % ("kernel", "hit rate", "requests (M)")]
+        tout = {}
+        for k in sorted(agg, key=lambda k: -(agg[k].get("TCC_HIT_sum", 0) + agg[k].get("TCC_MISS_sum", 0)))[:10]:
+            h, m = agg[k].get("TCC_HIT_sum", 0.0), agg[k].get("TCC_MISS_sum", 0.0)
+            if h + m <= 0:
+                continue
+            tout[k] = dict(hit_rate=h / (h + m), requests=h + m)
+            lines.append("%-40s %9.1f%% %16.1f" % (k, 100.0 * h / (h + m), (h + m) / 1e6))
+        json.dump(tout, open(os.path.join(a.dst, "tcc_hit_rate.json"), "w"), indent=1)
     open(os.path.join(a.dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
