@@ -425,6 +425,28 @@ def test_fp8_loss_curve_tracks_bf16_at_real_size():
     assert gap < 0.1 * lb[0], "largest absolute gap %.4f of an initial loss of %.4f" % (gap, lb[0])
 
 
+def test_fp8_loss_curve_on_distinct_learnable_batches():
+    """the same comparison where every batch is different and the task can be learnt (512 latent concepts, a fresh sample of
+    128 plus fresh pixel noise per step; benchmarks/fp8_loss_curve.py --structured runs the 400-step, batch-256 curves of
+    profiles/round3/): delayed scaling has to follow activations and gradients that change as training moves.  Both
+    precisions learn, and the fp8 loss stays within a factor of two of the bf16 one over the last 16 steps.  The peak is
+    1e-4 because at the shipped warm-up target of 5e-4 this task is unstable in EVERY precision, fp32 included: on the
+    shipped schedule (500 warm-up steps) all three spike at step ~20 (loss 6.3 .. 6.9) and what follows is luck -- fp8 ends
+    at 0.025, fp32 learns more slowly, bf16 stays at ln(batch); with 50 warm-up steps fp8 and bf16 both stay at ln(batch)
+    (profiles/round3/f*_loss_curve_structured_*.json).  A pointwise comparison there measures chaos, not precision."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
+    import fp8_loss_curve as FC
+    l8 = FC.run("fp8", steps=160, batch=128, peak_lr=1e-4, structured=True)
+    lb = FC.run("bf16", steps=160, batch=128, peak_lr=1e-4, structured=True)
+    tail = lambda x: sum(x[-16:]) / 16
+    print("fp8 vs bf16 on distinct learnable batches: first %.3f / %.3f, mean of the last 16 steps %.4f / %.4f" % (
+        l8[0], lb[0], tail(l8), tail(lb)))
+    assert all(math.isfinite(v) for v in l8)
+    assert tail(lb) < 0.5 * lb[0] and tail(l8) < 0.5 * l8[0], "both precisions must learn"
+    assert tail(l8) < 2.0 * tail(lb) + 0.05
+
+
 def test_fused_fp8_copies_equal_the_separate_quantise_pass():
     """LayerNorm forward / backward and the GEMM epilogue can emit the fp8 copy of their output themselves (fp8 mode's fused
     quantisation): same bytes and same amax as quantising the stored output afterwards"""
