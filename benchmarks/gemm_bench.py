@@ -57,6 +57,41 @@ def run(rounds=7, only=None, epi=False, sk=True):
     print("sum of best times: v5 %.1f us, v15 %.1f us" % (tot[5] * 1e3, tot[15] * 1e3))
 
 
+def run_grouped(rounds=7, targets=(512,)):
+    """the four weight gradients of a block: four launches (each split to ~384 workgroups, fp32 atomics) against ONE grouped launch"""
+    torch.manual_seed(0)
+    flush = torch.empty(128 * 1024 * 1024, device="cuda")
+    for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512), ("vitl14", 32896, 1024)):
+        dims = (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E))
+        prob = []
+        for name, n, k in dims:
+            dy = torch.randn(M, n, device="cuda").to(torch.bfloat16)
+            x = torch.randn(M, k, device="cuda").to(torch.bfloat16)
+            prob.append((dy, x, torch.zeros(n, k, device="cuda"), torch.zeros(n, device="cuda")))
+        best = {}
+        for r in range(rounds + 1):
+            for mode in ("4 launches",) + tuple("grouped@%d" % t for t in targets):
+                flush.zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if mode == "4 launches":
+                    for dy, x, gw, gb in prob:
+                        ops.gemm(dy, x, gw, trans_a=True, trans_b=True, accumulate=True, split_k=ops.wgrad_split(gw.shape[0], gw.shape[1], M),
+                                 a_rowsum=gb)
+                else:
+                    ops.wgrad_group(prob, M, target=int(mode.split("@")[1]))
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    best[mode] = min(best.get(mode, 1e9), e0.elapsed_time(e1))
+        fl = sum(2.0 * M * n * k for _, n, k in dims)
+        print("%-7s block weight gradients (rows %d): " % (tag, M) +
+              "  ".join("%s %6.1f us %6.1f TF/s" % (m, t * 1e3, fl / (t * 1e-3) / 1e12) for m, t in best.items()), flush=True)
+
+
 if __name__ == "__main__":
+    if "--grouped" in sys.argv:
+        run_grouped()
+        sys.exit(0)
     args = [x for x in sys.argv[1:] if not x.startswith("--")]
     run(only=args[0] if args else None, epi="--epi" in sys.argv, sk="--no-sk" not in sys.argv)

@@ -138,6 +138,28 @@ int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int ldb, void* p
  * per 64 x 64 tile of a weight (rows, cols and the offset multiples of 64).  fwd (same offsets) receives the trans_b = 0
  * image of W (the forward product X W^T), bwd the trans_b = 1 image (the input gradient dY W). */
 int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, const int32_t* table, int n_tiles, void* stream);
+/* Grouped weight gradients: gw_p[n_p, k_p] += dy_p^T x_p (and gb_p[n_p] += column sums of dy_p) for `count` nn.Linear layers
+ * that share their token rows -- the four linears of one residual attention block (autograd of F.linear at
+ * image_encoder/base_transformer.py:35-41,45-48; text twin text_encoder/base_transformer.py:33-48) -- as ONE launch over the
+ * concatenated 128 x 128 tile lists.  dy_p: [rows, n_p], x_p: [rows, k_p], row-major and compact, compute dtype
+ * ILVLM_BF16, or ILVLM_FP8_BF8A (dy e5m2, x e4m3, inv_g / inv_x = their de-quantisation scales on the device).
+ * split_target: workgroup slots of the chip for this kernel (512 = two per CU); the number of K-slices (1..16, >= 256 rows
+ * each) minimises ceil(tiles * slices / slots) * (ceil(K-tiles / slices) + e), e = 8 K-tiles' worth for the plain epilogue of
+ * one slice and 25 for the atomic one.  At one K-slice every tile has a single writer and is added with plain loads and
+ * stores; the caller guarantees that no OTHER launch accumulates into the same gw concurrently (launches on one stream are
+ * fine).  n_p, k_p multiples of 8 (fp8: 16). */
+#define ILVLM_WGRAD_GROUP_MAX 4
+typedef struct ilvlm_wgrad_problem {
+    const void* dy;
+    const void* x;
+    float* gw;          /* [n, k] fp32, accumulated */
+    float* gb;          /* [n] fp32, accumulated; or NULL */
+    int n, k;
+    const float* inv_g; /* fp8 only */
+    const float* inv_x; /* fp8 only */
+} ilvlm_wgrad_problem;
+int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* problems, int count, long rows, int split_target,
+                      void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-5 affine; base_transformer.py:10-18, clip_fdt.py:86-92) ----
  * y[r,:] = (x[R,:] - mean) * rstd * gamma + beta, R = map(r) when in_group > 0 (row remap as above:

@@ -131,6 +131,41 @@ int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, 
     return ilvlm_gemm(b->dtype, 0, 0, (int)M, N, K, x, K, W, K, y, N, &ep, 1, s);
 }
 
+// Weight gradients of one block collected for ONE grouped launch (ilvlm_wgrad_group) instead of four split-K launches:
+// linear_bwd appends its product here when `defer` is given and the product qualifies; flush_wgrad launches the list on
+// the weight-gradient stream behind an event on the input-gradient stream.  ILVLM_WGRAD_GROUP=0 switches it off.
+struct WgradBatch {
+    ilvlm_wgrad_problem p[ILVLM_WGRAD_GROUP_MAX];
+    int n = 0;
+    int dtype = -1;
+    long rows = 0;
+};
+
+int order_after(hipStream_t s, hipStream_t wg) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: hipEventCreate: %s", hipGetErrorString(e));
+    e = hipEventRecord(ev, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(wg, ev, 0);
+    hipError_t e2 = hipEventDestroy(ev);       // destruction is deferred until the event has completed
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: stream ordering: %s", hipGetErrorString(e));
+    return ILVLM_OK;
+}
+
+int flush_wgrad(WgradBatch* wb, hipStream_t s, hipStream_t wg) {
+    if (!wb || wb->n == 0) return ILVLM_OK;
+    static const int slots = getenv("ILVLM_WGRAD_GROUP_SLOTS") ? atoi(getenv("ILVLM_WGRAD_GROUP_SLOTS")) : 512;
+    hipStream_t ws = s;
+    if (wg && wg != s) {
+        TRY(order_after(s, wg));
+        ws = wg;
+    }
+    const int n = wb->n;
+    wb->n = 0;
+    return ilvlm_wgrad_group(wb->dtype, wb->p, n, wb->rows, slots, ws);
+}
+
 // dy [M,N], x [M,K], W [N,K] (compute dtype): accumulates dW (and db) on wg (or s when wg is null), writes dx on s.
 // dy8 / W8T / inv_*: the input gradient on fp8 operands (e5m2 dy, transposed e4m3 weight) when dy8 is given; x8 / inv_x: the
 // weight gradient on fp8 operands too (e5m2 dy^T, the e4m3 activation copy the forward pass kept), bias gradient as its row sums.
@@ -138,19 +173,27 @@ int linear_bwd(const ilvlm_block* b, int dtype, const void* dy, const void* x, c
                int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
                const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr, void* dx8 = nullptr,
                const float* dx8_scale = nullptr, float* dx8_amax = nullptr, const void* x8 = nullptr,
-               const float* inv_x = nullptr, const void* Wpt = nullptr) {
+               const float* inv_x = nullptr, const void* Wpt = nullptr, WgradBatch* defer = nullptr) {
     const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
-    if (gW || gb) {
+    const bool f8w = dy8 && x8;
+    const int wdt = f8w ? ILVLM_FP8_BF8A : dtype;
+    if (defer && gW && dtype == ILVLM_BF16 && (fuse_b || !gb) && N % (f8w ? 16 : 8) == 0 && K % (f8w ? 16 : 8) == 0 &&
+        defer->n < ILVLM_WGRAD_GROUP_MAX && (defer->n == 0 || (defer->dtype == wdt && defer->rows == M))) {
+        ilvlm_wgrad_problem& q = defer->p[defer->n++];
+        q.dy = f8w ? dy8 : dy;
+        q.x = f8w ? x8 : x;
+        q.gw = gW;
+        q.gb = gb;
+        q.n = N;
+        q.k = K;
+        q.inv_g = f8w ? inv_g : nullptr;
+        q.inv_x = f8w ? inv_x : nullptr;
+        defer->dtype = wdt;
+        defer->rows = M;
+    } else if (gW || gb) {
         hipStream_t ws = s;
         if (wg && wg != s) {     // weight gradients leave the dgrad chain (engine._linear_bwd)
-            hipEvent_t ev;
-            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: hipEventCreate: %s", hipGetErrorString(e));
-            e = hipEventRecord(ev, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(wg, ev, 0);
-            hipError_t e2 = hipEventDestroy(ev);       // destruction is deferred until the event has completed
-            if (e == hipSuccess) e = e2;
-            if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: stream ordering: %s", hipGetErrorString(e));
+            TRY(order_after(s, wg));
             ws = wg;
         }
         if (gW) {
@@ -320,12 +363,25 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // with fp8 weight gradients every consumer of du, d(x_mid)'s bf16 copy, dqkv and (when the caller takes din8) din_lp reads
     // the e5m2 copy: the bf16 tensors are not written
     if (f8wg) du = nullptr;
+    // Grouped weight gradients: the four products of the block as ONE launch (ilvlm_wgrad_group) once the last dY (dqkv)
+    // exists; the operands of all four stay alive in `saved` / `scratch` / the caller's dx until the caller joins the
+    // weight-gradient stream.  Measured (profiles/round3/step_ab_grouped*.txt): alone, the grouped launch is 17-21 % faster
+    // than the four split-K launches (ViT-B/32 block 316 -> 262 us, text block 192 -> 152 us, ViT-L/14 block 1061 -> 882 us:
+    // no atomics at one K-slice, one tail instead of four).  Inside the step the bf16 form LOSES -- 16.8 -> 17.1..17.4 ms
+    // (ViT-B/32 + FDT), 98.2 -> 101.9 ms (ViT-L/14), whatever the K-slices, with or without companion streams, with the
+    // launch capped to one workgroup per CU -- two towers already keep every CU supplied, so tails and atomics were never
+    // exposed, while one launch of 432 workgroups that live 260 us each holds the LDS of the whole chip against the
+    // input-gradient chain.  The fp8 form (single-stage, 32 KiB of LDS, three workgroups per CU) WINS: 13.31 -> 12.99 ms.
+    // Hence: ILVLM_WGRAD_GROUP unset = fp8 weight gradients only; 1 = always; 0 = never.
+    static const int group_env = getenv("ILVLM_WGRAD_GROUP") ? atoi(getenv("ILVLM_WGRAD_GROUP")) : -1;
+    WgradBatch batch;
+    WgradBatch* wb = (lp && (group_env > 0 || (group_env < 0 && f8wg))) ? &batch : nullptr;
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(b, T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
                    g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,
-                   f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G, b->proj_wpt));
+                   f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G, b->proj_wpt, wb));
     TRY(linear_bwd(b, T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
-                   f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2, b->fc_wpt));
+                   f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2, b->fc_wpt, wb));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
     if (f8wg) dmid_lp = nullptr;
     TRY(ilvlm_layernorm_bwd_q8(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
@@ -335,7 +391,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
     TRY(linear_bwd(b, T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT,
-                   b->out_wpt));
+                   b->out_wpt, wb));
     if (f8on) {                  // the attention backward kernels emit the e5m2 copy of dqkv themselves (all sequence lengths)
         if (f8wg) dqkv = nullptr;
         TRY(ilvlm_attention_bwd_q8(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, dqkv8, sc + F8_DQKV,
@@ -346,8 +402,36 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
         else TRY(ilvlm_attention_bwd(da, qkv, att, lse, dqkv, T, B, L, b->H, b->causal, s));
         TRY(f8_quant(b, dqkv, rows * 3 * E, F8_DQKV, 1, dqkv8, s, &g8));
     }
-    TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
-                   inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+    // the in-projection's weight gradient joins the batch and the grouped launch leaves BEFORE its input-gradient GEMM is
+    // enqueued: everything the four products read is final once the attention backward above has run
+    if (wb) {
+        const bool f8w = g8 && h1_8;
+        const int N = 3 * E, K = E;
+        if (b->g_in_w && (b->g_in_b == nullptr || N % 8 == 0) && wb->n < ILVLM_WGRAD_GROUP_MAX &&
+            (wb->n == 0 || (wb->dtype == (f8w ? ILVLM_FP8_BF8A : T) && wb->rows == rows))) {
+            ilvlm_wgrad_problem& q = wb->p[wb->n++];
+            q.dy = f8w ? g8 : (const void*)dqkv;
+            q.x = f8w ? h1_8 : h1;
+            q.gw = b->g_in_w;
+            q.gb = b->g_in_b;
+            q.n = N;
+            q.k = K;
+            q.inv_g = f8w ? inv + F8_DQKV : nullptr;
+            q.inv_x = f8w ? inv + F8_H1 : nullptr;
+            wb->dtype = f8w ? ILVLM_FP8_BF8A : T;
+            wb->rows = rows;
+            TRY(flush_wgrad(wb, s, wg));
+            TRY(linear_bwd(b, T, dqkv, h1, b->in_w, nullptr, nullptr, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
+                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+        } else {
+            TRY(flush_wgrad(wb, s, wg));
+            TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
+                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+        }
+    } else {
+        TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
+                       inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+    }
     return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32,
                                   lp ? din_lp : nullptr, T, 0,
                                   nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, din8, din8_scale, din8_amax, s);

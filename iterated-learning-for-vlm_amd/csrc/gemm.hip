@@ -24,6 +24,7 @@ struct EpiArgs {
     int vec_ok;    // N%4==0 && ldc%4==0 and all pointers 16B aligned
     int tile_group;   // store-type launches walk tiles in column groups of this width inside row bands (L2 blocking); 0 = off
     int tile_bands;   // number of row bands (8 = about one per XCD)
+    int plain_acc;    // accumulate launches: this launch is the only writer of C and split_k == 1 -> load-add-store, no atomics
 };
 
 // Handles 4 consecutive columns [n, n+4) of output row m.  AuxT = compute dtype.
@@ -698,10 +699,11 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
 // fragment read feeds two v_mfma_f32_16x16x32_fp8 (8 bytes = 8 k each; both operands split their bytes the same way, so
 // the products pair up whatever order k is visited in).  Half the operand bytes per FLOP of the bf16 kernel, which is
 // what bounds it.  K-contiguous operands only.
+// The body is shared by the single-problem kernel (gemm_bf16_dma_kernel) and the grouped weight-gradient kernel
+// (wgrad_group_kernel): `wg_linear` is the workgroup's index within ITS problem, already passed through xcd_remap.
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT, int FP8 = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
-                                                                     const bf16* __restrict__ B, int ldb, int K, int tiles_m,
-                                                                     int tiles_n, int split_k, EpiArgs ep) {
+__device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, int K,
+                                              int tiles_m, int tiles_n, int split_k, const EpiArgs& ep, int wg_linear) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * WM * WN;
     constexpr int TI = DBM / WM / 16, TJ = DBN / WN / 16;      // 16x16 tiles per wave
@@ -716,8 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int nwg = tiles_m * tiles_n * split_k;
-    int wg = xcd_remap(blockIdx.x, nwg);
+    int wg = wg_linear;
     const int tn = wg % tiles_n; wg /= tiles_n;
     // xcd_remap hands each XCD a contiguous range of wg.  Split-K (weight-gradient) launches order it K-slice major,
     // so one XCD's L2 sees one K-slice of both operands (each operand row is fetched by ~one XCD instead of all 8);
@@ -1015,6 +1016,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
                 }
                 epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
             }       // (the bias gradient of every slice still goes out below, as atomics on M floats)
+        } else if (ep.plain_acc && split_k == 1) {
+            // the only writer of this tile (grouped weight gradients at one K-slice): no atomics
+            epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
         } else {
             epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
         }
@@ -1037,6 +1041,43 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NST
     }
 #endif
 #endif   // __HIP_DEVICE_COMPILE__
+}
+
+template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT, int FP8 = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
+                                                                     const bf16* __restrict__ B, int ldb, int K, int tiles_m,
+                                                                     int tiles_n, int split_k, EpiArgs ep) {
+    dma_gemm_body<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT, FP8>(A, lda, B, ldb, K, tiles_m, tiles_n, split_k, ep,
+                                                                    xcd_remap(blockIdx.x, tiles_m * tiles_n * split_k));
+}
+
+// Grouped weight gradients: the (up to ILVLM_WGRAD_GROUP_MAX) products gW_p[N_p, K_p] += dY_p^T X_p of one transformer block --
+// same contraction length (the block's token rows), different outputs -- as ONE launch over the concatenated tile lists.
+// Why: launched one by one each product needs split-K slices to fill the chip (16..144 tiles of 128 x 128 against 512 workgroup
+// slots), and the slices meet in fp32 atomics on gW: 28 MB per ViT-B/32 fc product at the 1.3 TB/s atomics run at, 20 % of
+// that kernel's time, all workgroups reaching their epilogue together.  Grouped, the four products of a ViT-B/32 block are 432
+// tiles: one K-slice each fills the chip, every tile has one writer (plain load-add-store), and four launch tails become one.
+struct GroupProblem {
+    const bf16* A;       // dY [rows, N] (K-strided: the contraction runs over rows)
+    const bf16* B;       // X  [rows, K]
+    int lda, ldb, K, tiles_m, tiles_n, split_k, wg_begin, pad_;
+    EpiArgs ep;
+};
+struct GroupArgs {
+    GroupProblem p[ILVLM_WGRAD_GROUP_MAX];
+    int count, total;
+};
+
+template <int NSTAGE, int FP8>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void wgrad_group_kernel(GroupArgs g) {
+    const int wg = xcd_remap(blockIdx.x, g.total);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < ILVLM_WGRAD_GROUP_MAX; ++i)
+        if (i < g.count && wg >= g.p[i].wg_begin) pi = i;
+    const GroupProblem& P = g.p[pi];
+    dma_gemm_body<true, true, false, 128, 128, 2, 2, NSTAGE, 64, FP8>(P.A, P.lda, P.B, P.ldb, P.K, P.tiles_m, P.tiles_n, P.split_k,
+                                                                     P.ep, wg - P.wg_begin);
 }
 
 // =====================================================================================
@@ -1654,6 +1695,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     ep.ldc = ldc;
     ep.M = M;
     ep.N = N;
+    ep.plain_acc = 0;
     static const int tile_group_env = getenv("ILVLM_GEMM_TILE_GROUP") ? atoi(getenv("ILVLM_GEMM_TILE_GROUP")) : 4;
     static const int tile_kmax_env = getenv("ILVLM_GEMM_TILE_KMAX") ? atoi(getenv("ILVLM_GEMM_TILE_KMAX")) : 1024;
     static const int tile_bands_env = getenv("ILVLM_GEMM_TILE_BANDS") ? atoi(getenv("ILVLM_GEMM_TILE_BANDS")) : 8;
@@ -1757,6 +1799,9 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             // t is multiplied (64 KiB of LDS, two workgroups per CU).  Round 2 measured this form 3 % SLOWER; that build
             // was not pipelined at all (compiler-inserted vmcnt(0) behind the DMA builtin, see DmaOperand::issue).
             static const int wgrad_stages = getenv("ILVLM_WGRAD_STAGES") ? atoi(getenv("ILVLM_WGRAD_STAGES")) : 2;
+            // (Issuing the next K-tile's DMA pieces one by one between the MFMA groups, as the streaming kernel does, LOSES here:
+            // 585 against 515 us per block pair -- with two stages the loads need the whole compute phase to land, and a piece
+            // issued late is waited for at the top of the next step; profiles/round3/gemm_bench_wgrad_interleaved_issue.txt.)
             if (!swap && trans_a && trans_b && wgrad_stages == 2 && variant >= 15)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
 #define ILVLM_DMA(TA, TB)                                                                                            \
@@ -1815,6 +1860,89 @@ extern "C" int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, 
     hipLaunchKernelGGL(pack_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)arena_bf16, (bf16*)fwd,
                        (bf16*)bwd, table);
     ILVLM_LAUNCH_CHECK("pack_weights");
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* problems, int count, long rows, int split_target,
+                                 void* stream) {
+    ILVLM_REQUIRE(problems && count >= 1 && count <= ILVLM_WGRAD_GROUP_MAX, "wgrad_group: 1..%d problems", ILVLM_WGRAD_GROUP_MAX);
+    ILVLM_REQUIRE(compute_dtype == ILVLM_BF16 || compute_dtype == ILVLM_FP8_BF8A, "wgrad_group: bf16 or fp8 (e5m2 dy) operands");
+    ILVLM_REQUIRE(rows > 0 && rows < (1L << 31) && split_target > 0, "wgrad_group: bad rows / split_target");
+    const bool f8 = compute_dtype == ILVLM_FP8_BF8A;
+    const int ktile = f8 ? 128 : 64, K = (int)rows;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const ilvlm_wgrad_problem& q = problems[i];
+        ILVLM_REQUIRE(q.dy && q.x && q.gw && q.n > 0 && q.k > 0, "wgrad_group: problem %d: null pointer / bad shape", i);
+        ILVLM_REQUIRE(q.n % (f8 ? 16 : 8) == 0 && q.k % (f8 ? 16 : 8) == 0, "wgrad_group: problem %d: n, k must be multiples of %d",
+                      i, f8 ? 16 : 8);
+        ILVLM_REQUIRE(aligned(q.dy, 16) && aligned(q.x, 16) && aligned(q.gw, 4), "wgrad_group: problem %d: operand alignment", i);
+        ILVLM_REQUIRE(!f8 || (q.inv_g && q.inv_x), "wgrad_group: problem %d: fp8 operands need their scales", i);
+        tiles += (long)ceil_div(q.n, 128) * ceil_div(q.k, 128);
+    }
+    // K-slices: the count that minimises  rounds of workgroups x (K-tiles per slice + epilogue), in K-tile units -- a single
+    // writer adds its tile with plain loads and stores (~8 K-tiles' worth), K-slices meet in fp32 atomics (~25: they run at
+    // 1.3 TB/s and every workgroup of a round reaches them together).  ViT-B/32 block: 432 tiles -> 1 slice; text block:
+    // 192 tiles -> 2; ViT-L/14 block: 768 tiles -> 2 (three full rounds instead of one and a half).  ops.wgrad_group_split.
+    const int nt = ceil_div(K, ktile);
+    long cap = K >= 256 ? K / 256 : 1;
+    if (cap > 16) cap = 16;
+    if (cap > nt) cap = nt;
+    long split = 1;
+    double best = 1e30;
+    for (long sp = 1; sp <= cap; ++sp) {
+        const double rounds = (double)((tiles * sp + split_target - 1) / split_target);
+        const double c = rounds * ((double)((nt + sp - 1) / sp) + (sp == 1 ? 8.0 : 25.0));
+        if (c < best) { best = c; split = sp; }
+    }
+    GroupArgs g = {};
+    g.count = count;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        const ilvlm_wgrad_problem& q = problems[i];
+        GroupProblem& P = g.p[i];
+        P.A = (const bf16*)q.dy;
+        P.B = (const bf16*)q.x;
+        P.lda = q.n;
+        P.ldb = q.k;
+        P.K = K;
+        P.tiles_m = ceil_div(q.n, 128);
+        P.tiles_n = ceil_div(q.k, 128);
+        P.split_k = (int)split;
+        P.wg_begin = total;
+        total += P.tiles_m * P.tiles_n * (int)split;
+        P.ep.e.alpha = 1.0f;
+        P.ep.e.out_dtype = ILVLM_F32;
+        P.ep.e.accumulate = 1;
+        P.ep.e.a_rowsum = q.gb;
+        P.ep.e.alpha_ptr = f8 ? q.inv_g : nullptr;
+        P.ep.e.alpha_ptr2 = f8 ? q.inv_x : nullptr;
+        P.ep.Cf = q.gw;
+        P.ep.Cb = (bf16*)q.gw;
+        P.ep.ldc = q.k;
+        P.ep.M = q.n;
+        P.ep.N = q.k;
+        P.ep.vec_ok = (q.k % 4 == 0) && aligned(q.gw, 16);
+        P.ep.plain_acc = split == 1;
+    }
+    g.total = total;
+    hipStream_t s = (hipStream_t)stream;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    // ILVLM_WGRAD_GROUP_LDS: LDS bytes requested per workgroup beyond what the operand ring needs -- a way to cap the
+    // workgroups per CU of this (long-running) launch so that the input-gradient chain on the other stream keeps its share
+    static const int lds_env = getenv("ILVLM_WGRAD_GROUP_LDS") ? atoi(getenv("ILVLM_WGRAD_GROUP_LDS")) : 0;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "wgrad_group: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    const int lds8 = lds_env > 32768 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 32768;
+    const int lds16 = lds_env > 65536 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 65536;
+    if (f8) hipLaunchKernelGGL((wgrad_group_kernel<1, 3>), dim3(total), dim3(256), lds8, s, g);
+    else hipLaunchKernelGGL((wgrad_group_kernel<2, 0>), dim3(total), dim3(256), lds16, s, g);
+    ILVLM_LAUNCH_CHECK("wgrad_group");
     return ILVLM_OK;
 }
 

@@ -298,7 +298,7 @@ class Engine:
         if not self.concurrent_towers:
             return torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("ILVLM_SIDE_PRIO", "0")))
         return self._side
 
     # ------------------------------------------------------------------ parameters
@@ -355,7 +355,7 @@ class Engine:
         cur = torch.cuda.current_stream()
         key = cur.cuda_stream
         if key not in self._wg:
-            self._wg[key] = torch.cuda.Stream()
+            self._wg[key] = torch.cuda.Stream(priority=int(os.environ.get("ILVLM_WGRAD_PRIO", "0")))
         return self._wg[key]
 
     SLAB_BYTES, SLAB_TILES = 48 << 20, 4096

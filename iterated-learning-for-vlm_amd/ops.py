@@ -284,6 +284,51 @@ def pack_weights(arena_bf16, fwd, bwd, table):
                                         _stream()), "pack_weights")
 
 
+_WGRAD_GROUP_SLOTS = int(os.environ.get("ILVLM_WGRAD_GROUP_SLOTS", "512"))
+
+
+def wgrad_group_split(tiles, rows, slots=None, fp8=False):
+    """K-slices ilvlm_wgrad_group picks for `tiles` 128 x 128 output tiles over `rows` token rows (mirror of the C rule)"""
+    slots = slots or _WGRAD_GROUP_SLOTS
+    nt = -(-rows // (128 if fp8 else 64))
+    cap = min(16, nt, rows // 256 if rows >= 256 else 1)
+    best, split = None, 1
+    for sp in range(1, cap + 1):
+        c = -(-tiles * sp // slots) * (-(-nt // sp) + (8.0 if sp == 1 else 25.0))
+        if best is None or c < best:
+            best, split = c, sp
+    return split
+
+
+def wgrad_group(problems, rows, target=None, fp8=False):
+    """ONE launch for the weight (and bias) gradients of up to four linears that share their token rows.  problems: list of
+    (dy [rows, n], x [rows, k], gw fp32 [n, k], gb fp32 [n] or None[, inv_g, inv_x]); bf16 operands, or fp8 (dy e5m2 /
+    x e4m3 as uint8, with their de-quantisation scale tensors).  Accumulates; see ilvlm_wgrad_group for the single-writer rule."""
+    if not 1 <= len(problems) <= L.WGRAD_GROUP_MAX:
+        raise RuntimeError("wgrad_group: 1..%d problems" % L.WGRAD_GROUP_MAX)
+    arr = (L.WgradProblem * len(problems))()
+    od = torch.uint8 if fp8 else torch.bfloat16
+    for i, pr in enumerate(problems):
+        dy, x, gw, gb = pr[:4]
+        _chk(dy, "wgrad_group.dy", od)
+        _chk(x, "wgrad_group.x", od)
+        _chk(gw, "wgrad_group.gw", torch.float32)
+        if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != rows or x.shape[0] != rows or tuple(gw.shape) != (dy.shape[1], x.shape[1]):
+            raise RuntimeError("wgrad_group: problem %d: dy [rows, n], x [rows, k], gw [n, k] expected, got %s %s %s" % (
+                i, tuple(dy.shape), tuple(x.shape), tuple(gw.shape)))
+        if gb is not None:
+            _chk(gb, "wgrad_group.gb", torch.float32)
+            if gb.numel() != dy.shape[1]:
+                raise RuntimeError("wgrad_group: problem %d: gb must have n elements" % i)
+        arr[i].dy, arr[i].x, arr[i].gw = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+        arr[i].gb = gb.data_ptr() if gb is not None else None
+        arr[i].n, arr[i].k = dy.shape[1], x.shape[1]
+        if fp8:
+            arr[i].inv_g, arr[i].inv_x = pr[4].data_ptr(), pr[5].data_ptr()
+    L.check(L.load().ilvlm_wgrad_group(L.FP8_BF8A if fp8 else L.BF16, arr, len(problems), int(rows),
+                                       int(target if target is not None else _WGRAD_GROUP_SLOTS), _stream()), "wgrad_group")
+
+
 def gemm_set_variant(v):
     L.check(L.load().ilvlm_gemm_set_variant(int(v)), "gemm_set_variant")
 

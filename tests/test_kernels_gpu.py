@@ -824,6 +824,42 @@ def test_slab_split_k_weight_gradient_is_right_and_bit_reproducible(M, N, K, spl
     assert int(slab[1].abs().sum()) == 0                 # every ticket counter is back at zero
 
 
+@pytest.mark.parametrize("rows,E,target", [(12800, 768, 512), (11319, 512, 512), (11319, 512, 2000), (1000, 192, 512), (77, 64, 512)])
+def test_grouped_weight_gradients(rows, E, target):
+    """the four weight gradients of a block as ONE launch (ilvlm_wgrad_group): every product and bias gradient equal to the
+    fp32 reference, accumulating into what the gradient slots already hold.  At one K-slice (the ViT-B/32 block: 432 tiles)
+    every tile has a single writer: plain load-add-store instead of atomics, so repeated launches are bit-identical and equal,
+    bit for bit, to the single launches at split_k = 1 (same MFMA sequence); with K-slices (the text block) atomics again."""
+    ops = _ops()
+    dims = ((3 * E, E), (E, E), (4 * E, E), (E, 4 * E))
+    prob, refs = [], []
+    for i, (n, k) in enumerate(dims):
+        dy = rnd(rows, n, seed=10 + i).to(torch.bfloat16).cuda()
+        x = rnd(rows, k, seed=20 + i).to(torch.bfloat16).cuda()
+        base = rnd(n, k, seed=30 + i).cuda() * 50
+        bb = rnd(n, seed=40 + i).cuda() * 50
+        prob.append((dy, x, base.clone(), bb.clone()))
+        refs.append((base, bb, dy.float().t() @ x.float(), dy.float().sum(0)))
+    ops.wgrad_group(prob, rows, target=target)
+    for (dy, x, gw, gb), (base, bb, ref, rs) in zip(prob, refs):
+        assert float((gw - base - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+        assert float((gb - bb - rs).abs().max()) < 1e-3 * float(rs.abs().max())
+    tiles = sum(-(-n // 128) * -(-k // 128) for n, k in dims)
+    assert ops.wgrad_group_split(432, 12800, 512) == 1 and ops.wgrad_group_split(192, 11319, 512) == 2
+    assert ops.wgrad_group_split(768, 32896, 512) == 2
+    if ops.wgrad_group_split(tiles, rows, target) == 1:    # single-writer form
+        again = [(dy, x, base.clone(), bb.clone()) for (dy, x, _, _), (base, bb, _, _) in zip(prob, refs)]
+        ops.wgrad_group(again, rows, target=target)
+        for (_, _, gw, _), (_, _, gw2, _) in zip(prob, again):
+            assert torch.equal(gw, gw2)
+        for (dy, x, gw, _), (base, _, _, _) in zip(prob, refs):
+            one = base.clone()
+            ops.gemm(dy, x, one, trans_a=True, trans_b=True, accumulate=True, split_k=1)
+            assert torch.equal(gw, one)
+    with pytest.raises(RuntimeError):
+        ops.wgrad_group(prob + prob[:1], rows)             # more than ILVLM_WGRAD_GROUP_MAX problems
+
+
 @pytest.mark.parametrize("B,L,H,causal,packed", [(256, 77, 8, 1, True), (256, 50, 12, 0, False), (64, 257, 16, 0, False)])
 def test_attention_at_full_size_is_deterministic_and_right(B, L, H, causal, packed):
     """the step's attention launches at full size: repeated launches bit-identical (no atomics), a sample of sequences equal to

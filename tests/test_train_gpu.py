@@ -465,3 +465,56 @@ def test_adamw_issued_from_inside_backward_is_bit_identical(precision):
         for g, w in zip(got, want):
             assert torch.equal(g, w)
         opt.overlap_backward(True)
+
+
+_GROUP_SCRIPT = r"""
+import sys, os, json, hashlib
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from configs import CFG, FDT_VARIANTS, model_kwargs, state_shapes
+from detfill import det_state, det_images, det_tokens
+from ilvlm_amd.prototype.model import model_entry
+from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+c, v = CFG["a"], FDT_VARIANTS[0]
+kw = model_kwargs(c, v); kw["precision"] = PREC
+model = model_entry(dict(type="clip_fdt_vitb32", kwargs=kw))
+model.load_state_dict({k: torch.from_numpy(a) for k, a in det_state(state_shapes(c, True), 11).items()})
+model.cuda().train()
+crit = ClipInfoCELoss()
+out = {}
+for step in range(1, 4):            # fp8: the first step only observes, the later ones run on fp8 operands
+    tok, mask = det_tokens(c["batch"], c["ctx"], 300 + step)
+    img = torch.from_numpy(det_images(c["batch"], c["res"], 300 + step)).cuda()
+    (li, lt), _ = model(img, (torch.from_numpy(tok), torch.from_numpy(mask)))
+    loss, _ = crit(li, lt)
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    out["loss%d" % step] = float(loss)
+g = model._eng.arena.G.detach().float().cpu().numpy()
+np.save(OUT, g)
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_grouped_weight_gradients_in_the_block_path(precision, tmp_path):
+    """ILVLM_WGRAD_GROUP (read once per process, hence two child processes): the composite block backward with its four weight
+    gradients as one grouped launch (1) against four split-K launches (0) -- the same losses and, up to the summation order
+    of the K-slices, the same gradient arena.  bf16: grouping is opt-in; fp8 weight gradients: it is the default."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("g%s.npy" % flag))
+        src = "ROOT=%r\nPREC=%r\nOUT=%r\n" % (root, precision, out) + _GROUP_SCRIPT
+        env = dict(os.environ, ILVLM_WGRAD_GROUP=flag)
+        r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = (json.loads(r.stdout.strip().splitlines()[-1]), np.load(out))
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-3 * abs(l0[k]), (k, l0[k], l1[k])
+    assert np.isfinite(g1).all() and np.abs(g0).max() > 0
+    tol = 2e-3 if precision == "bf16" else 2e-2      # fp8: the second step's scales come from amax values gathered by atomics
+    assert np.abs(g1 - g0).max() <= tol * np.abs(g0).max(), np.abs(g1 - g0).max() / np.abs(g0).max()
