@@ -315,6 +315,11 @@ int ilvlm_scale_dev(const float* x, float* y, const float* a, long n, void* stre
 int ilvlm_add_inplace(float* y, const float* x, long n, void* stream);
 /* x = min(max(x, lo), hi) in place (logit_scale.data.clamp_, train_solver.py:381-382, 397-398) */
 int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream);
+/* Gradient-norm clipping over the flat gradient arena (grad_clip.type 'norm': clip_grad_norm_, prototype/utils/grad_clip.py:12-47,
+ * called at train_solver.py:403-405): out[0] += sum x^2 (zero it first), then x *= max_norm / (sqrt(sumsq[0]) + 1e-6) when that
+ * factor is below 1; the norm never leaves the device. */
+int ilvlm_sumsq(const float* x, long n, float* out, void* stream);
+int ilvlm_clip_by_norm(float* x, long n, const float* sumsq, float max_norm, void* stream);
 
 /* ---- fused multi-tensor AdamW (torch.optim.AdamW semantics, optimizer/__init__.py:3,18-26).
  * The parameters live in one flat fp32 arena; `chunk_*` arrays (device) describe n_chunks pieces:

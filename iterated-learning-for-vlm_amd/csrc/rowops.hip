@@ -435,6 +435,21 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, float
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
+// out[0] += sum x^2 (one atomic per workgroup); x *= min(1, max_norm / (sqrt(ss[0]) + 1e-6)): clip_grad_norm_ over the flat
+// gradient arena (prototype/utils/grad_clip.py:12-47)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float scratch[8];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+__global__ __launch_bounds__(256) void clip_by_norm_kernel(float* __restrict__ x, long n, const float* __restrict__ ss, float max_norm) {
+    const float coef = max_norm / (sqrtf(ss[0]) + 1e-6f);
+    if (!(coef < 1.f)) return;               // the reference multiplies only when the norm exceeds the bound
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= coef;
+}
+
 inline int grid_1d(long n, int per_block, int cap = 4096) {
     long g = (n + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -802,6 +817,18 @@ extern "C" int ilvlm_scale_dev(const float* x, float* y, const float* a, long n,
     ILVLM_REQUIRE(x && y && a && n > 0, "scale_dev: bad args");
     hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, S_, x, y, a, n);
     ILVLM_LAUNCH_CHECK("scale_dev");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_sumsq(const float* x, long n, float* out, void* stream) {
+    ILVLM_REQUIRE(x && out && n > 0, "sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_1d(n, 1024, 4096)), dim3(256), 0, S_, x, n, out);
+    ILVLM_LAUNCH_CHECK("sumsq");
+    return ILVLM_OK;
+}
+extern "C" int ilvlm_clip_by_norm(float* x, long n, const float* sumsq, float max_norm, void* stream) {
+    ILVLM_REQUIRE(x && sumsq && n > 0 && max_norm > 0.f, "clip_by_norm: bad args");
+    hipLaunchKernelGGL(clip_by_norm_kernel, dim3(grid_1d(n, 1024, 4096)), dim3(256), 0, S_, x, n, sumsq, max_norm);
+    ILVLM_LAUNCH_CHECK("clip_by_norm");
     return ILVLM_OK;
 }
 extern "C" int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream) {

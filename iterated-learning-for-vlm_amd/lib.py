@@ -96,6 +96,8 @@ SIGNATURES = {
     "ilvlm_scale_dev": [vp, vp, vp, i64, vp],
     "ilvlm_add_inplace": [vp, vp, i64, vp],
     "ilvlm_clamp": [vp, f32, f32, i64, vp],
+    "ilvlm_sumsq": [vp, i64, vp, vp],
+    "ilvlm_clip_by_norm": [vp, i64, vp, f32, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
     "ilvlm_block_saved_bytes": [C.POINTER(Block), i64, i32, i32],

@@ -762,6 +762,17 @@ def add_inplace(y, x):
     return y
 
 
+def clip_grad_norm_(flat, max_norm, scratch=None):
+    """clip_grad_norm_ (2-norm) over a flat fp32 gradient buffer, entirely on the device; returns the 1-element tensor holding
+    the SQUARED total norm (read it only when logging)"""
+    _chk(flat, "clip_grad_norm.flat", torch.float32)
+    ss = scratch if scratch is not None else torch.empty(1, dtype=torch.float32, device=flat.device)
+    ss.zero_()
+    L.check(L.load().ilvlm_sumsq(flat.data_ptr(), flat.numel(), ss.data_ptr(), _stream()), "sumsq")
+    L.check(L.load().ilvlm_clip_by_norm(flat.data_ptr(), flat.numel(), ss.data_ptr(), float(max_norm), _stream()), "clip_by_norm")
+    return ss
+
+
 def clamp_(x, lo, hi):
     _chk(x, "clamp.x", torch.float32)
     L.check(L.load().ilvlm_clamp(x.data_ptr(), float(lo), float(hi), x.numel(), _stream()), "clamp")

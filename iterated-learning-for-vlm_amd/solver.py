@@ -305,6 +305,9 @@ class ClsSolver:
         # between), which is what the in-backward update needs
         # (opt-in: on one GPU it measured +-0, the chip is already full during backward)
         if os.environ.get("ILVLM_ADAMW_IN_BACKWARD", "0") == "1":
+            if self.config.grad_clip.type in self.GRAD_CLIPS:
+                raise ValueError("ILVLM_ADAMW_IN_BACKWARD=1 updates blocks before backward ends; grad_clip.type=%r needs the "
+                                 "complete gradient first" % self.config.grad_clip.type)
             self.optimizer.overlap_backward(True)
         if "optimizer" in self.state and not self.fdt:
             # the baseline solver restores optimizer state (example/clip/train_solver.py:279-280); the FDT solver does not
@@ -349,17 +352,71 @@ class ClsSolver:
         if eng is not None:
             eng.mark_dirty()
 
-    def _clamp_logit_scale(self):
+    # grad_clip.type, all of the reference's (train_solver.py:374-415, 467-470), every one without a host read:
+    #   parameter clips   logit_scale_param_value | logit_scale_param_abs_min | constant | logit_scale_param (the step may move
+    #                     logit_scale by at most `value`) | logit_scale_param_ema (EMA_logit_scale, train_solver.py:61-83)
+    #   gradient clips    norm | value | logit_scale_grad  (prototype/utils/grad_clip.py), applied between backward and step
+    PARAM_CLIPS = ("logit_scale_param_value", "logit_scale_param_abs_min", "constant", "logit_scale_param", "logit_scale_param_ema")
+    GRAD_CLIPS = ("norm", "value", "logit_scale_grad")
+
+    def _param_clip_before(self):
         gc = self.config.grad_clip
         from . import ops
+        ls = self.model.module.logit_scale
         if gc.type == "logit_scale_param_value":
-            ops.clamp_(self.model.module.logit_scale.data, gc.value, gc.max_value)
+            ops.clamp_(ls.data, gc.value, gc.max_value)
         elif gc.type == "logit_scale_param_abs_min":
-            ops.clamp_(self.model.module.logit_scale.data, gc.value, float("inf"))
+            ops.clamp_(ls.data, gc.value, float("inf"))
         elif gc.type == "constant":
-            self.model.module.logit_scale.requires_grad = False
+            ls.requires_grad = False
+        elif gc.type == "logit_scale_param":
+            self._ls_before = ls.data.clone()                       # the reference reads .item() here: a host sync per step
+        elif gc.type not in self.GRAD_CLIPS and gc.type != "logit_scale_param_ema":
+            raise NotImplementedError("grad_clip.type=%r" % gc.type)
+
+    def _param_clip_after(self):
+        gc = self.config.grad_clip
+        from . import ops
+        ls = self.model.module.logit_scale
+        if gc.type == "logit_scale_param_value":
+            ops.clamp_(ls.data, gc.value, gc.max_value)
+        elif gc.type == "logit_scale_param_abs_min":
+            ops.clamp_(ls.data, gc.value, float("inf"))
+        elif gc.type == "logit_scale_param":
+            # after - before > value -> before + value; before - after > value -> before - value: a clamp around `before`
+            ls.data.copy_(torch.minimum(torch.maximum(ls.data, self._ls_before - gc.value), self._ls_before + gc.value))
+
+    def _grad_clip_before(self):
+        """between backward and optimizer.step() (train_solver.py:402-411, 431), on the flat gradient arena"""
+        gc = self.config.grad_clip
+        if gc.type not in self.GRAD_CLIPS:
+            return
+        from . import ops
+        eng = self.model.module.engine
+        arena = eng.arena
+        arena.wait_grads()                  # the data-parallel mean of every range has to be in before gradients are judged
+        if gc.type == "norm":
+            # parameters without a gradient hold zeros in the arena and add nothing to the norm (the reference skips them)
+            self.grad_norm_sq = ops.clip_grad_norm_(arena.G, gc.value, getattr(self, "grad_norm_sq", None))
+        elif gc.type == "value":
+            ops.clamp_(arena.G, -gc.value, gc.value)
         else:
-            raise NotImplementedError("grad_clip.type=%r (shipped configs use logit_scale_param_value)" % gc.type)
+            ops.clamp_(eng.Gr["logit_scale"].view(-1), -gc.value, gc.value)
+
+    def _ema_clip(self):
+        """EMA_logit_scale.clamp() then .update() at the end of the iteration (train_solver.py:61-83, 467-470): logit_scale may
+        stray at most `value` from its running mean (momentum 0.9, start 3.125); clip_number counts the clamps on the device"""
+        gc = self.config.grad_clip
+        if gc.type != "logit_scale_param_ema":
+            return
+        ls = self.model.module.logit_scale
+        if getattr(self, "_ema_buf", None) is None:
+            self._ema_buf = torch.full_like(ls.data, 3.125)
+            self.clip_number = torch.zeros((), dtype=torch.int64, device=ls.device)
+        lo, hi = self._ema_buf - gc.value, self._ema_buf + gc.value
+        self.clip_number += ((ls.data > hi) | (ls.data < lo)).sum()
+        ls.data.copy_(torch.minimum(torch.maximum(ls.data, lo), hi))
+        self._ema_buf.mul_(0.9).add_(ls.data, alpha=0.1)
 
     def _temperature(self, curr_step):
         td = self.config.get("t_decay")
@@ -381,10 +438,12 @@ class ClsSolver:
             loss = loss / self.world_size
         prec1, prec5 = accuracy(logits[0], target, topk=(1, self.topk))
         self.optimizer.zero_grad()
-        self._clamp_logit_scale()
+        self._param_clip_before()
         loss.backward()
+        self._grad_clip_before()
         self.optimizer.step()
-        self._clamp_logit_scale()
+        self._param_clip_after()
+        self._ema_clip()
         return loss, prec1 / self.world_size, prec5 / self.world_size
 
     def save_checkpoint(self, curr_step):

@@ -518,3 +518,96 @@ def test_grouped_weight_gradients_in_the_block_path(precision, tmp_path):
     assert np.isfinite(g1).all() and np.abs(g0).max() > 0
     tol = 2e-3 if precision == "bf16" else 2e-2      # fp8: the second step's scales come from amax values gathered by atomics
     assert np.abs(g1 - g0).max() <= tol * np.abs(g0).max(), np.abs(g1 - g0).max() / np.abs(g0).max()
+
+
+def _clip_solver(tmp_path, gc, precision="fp32"):
+    import yaml
+    from ilvlm_amd import solver as S
+    c = CFG["a"]
+    cfg = dict(
+        model=dict(type="clip_fdt_vitb32", kwargs=model_kwargs(c, FDT_VARIANTS[0])),
+        grad_clip=gc,
+        t_decay=dict(org_t=1000, sd_T_decay_iter=100, sd_T_decay_w=0.5, sd_T_min=0.01),
+        optimizer=dict(type="AdamW", kwargs=dict(lr=5e-3, weight_decay=0.1, betas=[0.9, 0.98], amsgrad=False, eps=1e-8),
+                       pconfig={k: dict(weight_decay=0) for k in ("bn_w", "bn_b", "ln_w", "ln_b", "bias", "logit_scale")}),
+        lr_scheduler=dict(type="Cosine", kwargs=dict(base_lr=5e-3, warmup_lr=5e-3, min_lr=0.0, warmup_steps=2, max_iter=40)),
+        data=dict(train=dict(epoch=1, batch_size=8, num_samples=8 * 12, num_shards=1, workers=0, transforms="none",
+                             data_path="none"), test=dict()),
+        saver=dict(print_freq=2, val_freq=100, save_freq=500, save_many=True),
+        reset=dict(enable=False, reset_steps=300, reset_nums=4, save_freq=1, smooth_steps=1, distil_steps=0))
+    cfg["model"]["kwargs"]["precision"] = precision
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    args = S.argparse.Namespace(config=str(path), output_path=str(tmp_path / "out"), batch_size=8, debug=True, exp_name="c",
+                                ckpt_path="", synthetic=True, max_steps=3, lipreg=0)
+    sol = S.ClsSolver(args)
+    sol.model.train()
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    sol.criterion = ClipInfoCELoss()
+    sol.topk = 5
+    return sol
+
+
+@pytest.mark.parametrize("gtype", ["norm", "value", "logit_scale_grad", "logit_scale_param", "logit_scale_param_ema",
+                                   "logit_scale_param_abs_min", "constant"])
+def test_every_grad_clip_type_of_the_reference(gtype, tmp_path):
+    """grad_clip.type beyond the shipped logit_scale_param_value (train_solver.py:61-83, 374-415, 467-470;
+    prototype/utils/grad_clip.py): each against the reference's arithmetic applied to the gradients / values this run itself
+    produced, with no host read inside the step."""
+    value = {"norm": 0.05, "value": 1e-4, "logit_scale_grad": 1e-3, "logit_scale_param": 1e-3, "logit_scale_param_ema": 0.05,
+             "logit_scale_param_abs_min": 4.7, "constant": 0.0}[gtype]
+    sol = _clip_solver(tmp_path, dict(type=gtype, value=value, max_value=6))
+    m = sol.model.module
+    arena = None
+    seen = {}
+    import ilvlm_amd.ops as ops
+    real_step = sol.optimizer.step
+
+    def spy_step():                      # the gradient the optimizer is handed
+        seen["G"] = m.engine.arena.G.detach().clone()
+        return real_step()
+    sol.optimizer.step = spy_step
+    real_clip = sol._grad_clip_before
+
+    def spy_clip():
+        seen["raw"] = m.engine.arena.G.detach().clone()
+        return real_clip()
+    sol._grad_clip_before = spy_clip
+    image, text = next(iter(getattr(sol.train_data, "dataloader", sol.train_data)))
+    for step in (1, 2, 3):
+        ls0 = m.logit_scale.detach().clone()
+        sol.train_step(image, text, step)
+        torch.cuda.synchronize()
+        raw, G = seen["raw"], seen["G"]
+        if gtype == "norm":
+            tn = torch.linalg.vector_norm(raw.double()).float()
+            coef = value / (tn + 1e-6)
+            want = raw * coef if coef < 1 else raw
+            assert float(tn) > value, "the bound must bite for the test to mean something"
+            assert float((G - want).abs().max()) <= 1e-5 * float(want.abs().max())
+            assert abs(float(torch.linalg.vector_norm(G.double())) - value) < 1e-3 * value
+            assert abs(float(sol.grad_norm_sq) - float(tn) ** 2) < 1e-3 * float(tn) ** 2
+        elif gtype == "value":
+            assert float(raw.abs().max()) > value
+            assert torch.equal(G, raw.clamp(-value, value))
+        elif gtype == "logit_scale_grad":
+            o = m.engine.arena.offsets["logit_scale"]
+            want = raw.clone()
+            want[o] = want[o].clamp(-value, value)
+            assert torch.equal(G, want)
+        else:
+            assert torch.equal(G, raw)
+        ls1 = m.logit_scale.detach()
+        if gtype == "logit_scale_param":        # AdamW at lr 5e-3 moves the scalar by ~5e-3 per step: the clamp to +-1e-3 bites
+            assert abs(float(ls1 - ls0)) <= value * (1 + 1e-6) and abs(float(ls1 - ls0)) > 0.5 * value
+        elif gtype == "logit_scale_param_abs_min":
+            assert float(ls1) >= float(np.float32(value))
+        elif gtype == "constant":       # (the reference flips the flag after its first forward, so ITS first step still moves the
+            assert torch.equal(ls1, ls0) and not m.logit_scale.requires_grad    # scalar once; here it is frozen from step one)
+    if gtype == "logit_scale_param_ema":
+        # ln(1/0.07) = 2.659 starts 0.466 away from the 3.125 the running mean starts at: clamped to within 0.05 of it each step
+        assert 1 <= int(sol.clip_number) <= 3
+        assert abs(float(m.logit_scale.detach()) - float(sol._ema_buf)) <= 0.05 / 0.9 + 1e-6
+    with pytest.raises(NotImplementedError):
+        bad = _clip_solver(tmp_path, dict(type="no_such_clip", value=1.0, max_value=6))
+        bad.train_step(image, text, 1)
