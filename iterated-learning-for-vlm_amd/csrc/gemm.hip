@@ -1801,7 +1801,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             static const int wgrad_stages = getenv("ILVLM_WGRAD_STAGES") ? atoi(getenv("ILVLM_WGRAD_STAGES")) : 2;
             // (Issuing the next K-tile's DMA pieces one by one between the MFMA groups, as the streaming kernel does, LOSES here:
             // 585 against 515 us per block pair -- with two stages the loads need the whole compute phase to land, and a piece
-            // issued late is waited for at the top of the next step; profiles/round3/gemm_bench_wgrad_interleaved_issue.txt.)
+            // issued late is waited for at the top of the next step; profiles/round3/gemm_bench_wgrad_interleaved_issue.txt.
+            // Giving the interleaved loads a whole step of slack -- THREE stages of 32-deep K-tiles, 48 KiB, three workgroups
+            // per CU -- loses too: 547 us per block pair alone, 17.19 against 16.88 ms in the step (twice the barriers per
+            // MFMA); profiles/round3/gemm_bench_wgrad_3stage_bk32.txt.  Both forms are in the git history.)
             if (!swap && trans_a && trans_b && wgrad_stages == 2 && variant >= 15)
                 return launch_dma<true, true, false, 128, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
 #define ILVLM_DMA(TA, TB)                                                                                            \
