@@ -7,12 +7,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops
 
+# selectors timed side by side: 5 and 15 always; GEMM_BENCH_VARIANTS=5,15,8 adds the 256x256 phased kernel
+VARIANTS = tuple(int(x) for x in os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(","))
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
     for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E)):
         SHAPES.append((tag + "." + name + ".fwd", 0, 0, M, n, k, False, 1))
         SHAPES.append((tag + "." + name + ".dgrad", 0, 1, M, k, n, False, 1))
         SHAPES.append((tag + "." + name + ".wgrad", 1, 1, n, k, M, True, ops.wgrad_split(n, k, M)))
+SHAPES.append(("sq4096", 0, 0, 4096, 4096, 4096, False, 1))        # the guides' reference shape
 SHAPES.append(("fdt.img.scores", 0, 0, 12544, 4096, 512, False, 1))
 SHAPES.append(("fdt.txt.scores", 0, 0, 19712, 4096, 512, False, 1))
 
@@ -22,7 +25,7 @@ def run(rounds=7, only=None, epi=False, sk=True):
     flush = torch.empty(128 * 1024 * 1024, device="cuda")
     # slab workspace for the store-type split-K of the streaming kernel (what the engine offers per stream)
     slab = (torch.empty(160 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(8192, dtype=torch.int32, device="cuda")) if sk else None
-    tot = {5: 0.0, 15: 0.0}
+    tot = {v: 0.0 for v in VARIANTS}
     for (tag, ta, tb, M, N, K, acc, split) in SHAPES:
         if only and only not in tag:
             continue
@@ -33,7 +36,7 @@ def run(rounds=7, only=None, epi=False, sk=True):
         if epi and not acc:        # the MLP up-projection's epilogue: bias + QuickGELU with the pre-activation stored
             kw = dict(bias=torch.randn(N, device="cuda"), aux=torch.empty(M, N, device="cuda", dtype=torch.bfloat16), act=1)
         packed = None if acc else ops.gemm_pack_b(b, trans_b=bool(tb))
-        variants = (5, 15)
+        variants = VARIANTS
         best = {v: 1e9 for v in variants}
         for r in range(rounds + 1):
             for v in variants:
@@ -54,7 +57,7 @@ def run(rounds=7, only=None, epi=False, sk=True):
               "  ".join("v%d %7.1f TF/s (%6.1f us)" % (v, fl / (best[v] * 1e-3) / 1e12, best[v] * 1e3) for v in variants) +
               "   x%.2f" % (best[5] / best[15]), flush=True)
     ops.gemm_set_variant(15)
-    print("sum of best times: v5 %.1f us, v15 %.1f us" % (tot[5] * 1e3, tot[15] * 1e3))
+    print("sum of best times: " + ", ".join("v%d %.1f us" % (v, tot[v] * 1e3) for v in VARIANTS))
 
 
 def run_grouped(rounds=7, targets=(512,)):
