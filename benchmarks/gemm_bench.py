@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops
 
-# selectors timed side by side: 5 and 15 always; GEMM_BENCH_VARIANTS=5,15,8 adds the 256x256 phased kernel
+# selectors timed side by side (GEMM_BENCH_VARIANTS=5,15 by default)
 VARIANTS = tuple(int(x) for x in os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(","))
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):

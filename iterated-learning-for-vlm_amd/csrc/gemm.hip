@@ -425,26 +425,11 @@ struct DmaOperand {
     // of the reads of a stage, ILVLM_WG_BARRIER).  M0 (the LDS destination) is written and read inside the statement; the
     // instruction between an M0 write and the load is the wait state that pair needs.
     __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
-        static_assert(NLOAD == 4 || NLOAD == 2, "four 1 KiB pieces per wave and operand (128-row operand, 256 threads) or two (512 threads)");
+        static_assert(NLOAD == 4, "four 1 KiB pieces per wave and operand (128-row operand, 256 threads)");
         const int soff = tile_off + t * k_step + extra;
         const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)tile + wave * (NLOAD * 1024);
         const pk_i32x4 r4 = rs;
-        if constexpr (NLOAD == 2 && TR) {
-            asm volatile(
-                "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds"
-                :
-                : [v0] "v"(voff[0]), [v1] "v"(voff[TR ? 1 : 0]), [rs] "s"(r4), [so] "s"(soff), [lds] "s"(lds)
-                : "memory", "scc");
-        } else if constexpr (NLOAD == 2) {
-            int tmp;
-            asm volatile(
-                "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[so]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds"
-                : [t] "=&s"(tmp)
-                : [v0] "v"(voff[0]), [rs] "s"(r4), [so] "s"(soff), [js] "s"(jstep), [lds] "s"(lds)
-                : "memory", "scc");
-        } else if constexpr (TR) {
+        if constexpr (TR) {
             asm volatile(
                 "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
@@ -1096,234 +1081,6 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void wgrad_group_kernel(G
 }
 
 // =====================================================================================
-// bf16 "phased" kernel (round 2's design, back in round 3 for a measurement on DMA that really stays in flight: in
-// round 2 hipcc drained every LDS-DMA builtin in front of the next ds_read, see DmaOperand::issue): 256x256x64 tile, 8 waves as
-// 2 (M) x 4 (N), one workgroup per CU, 128 KiB of LDS =
-// two K-tile buffers of four 16 KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255).
-//
-// A 256x256 tile needs half the L2->LDS bytes per FLOP of the 128x128 kernel above (whose operand DMA and MFMA time
-// per K-tile are equal at the CU's 64 B/clk, so neither can be hidden behind the other).  The K-tile is cut into four
-// phases of {LOAD section: fragment ds_reads of one quadrant's operands + the DMA of one half-tile of a later K-tile;
-// COMPUTE section: 16 MFMAs = one 64x32 quadrant of the wave's 128x64 output x K = 64}, every section closed by a
-// workgroup barrier.  Waves 4-7 (the second wave of every SIMD) run one section behind waves 0-3, so on each SIMD one
-// wave's MFMAs cover the other's LDS reads and DMA issue.  DMA stays in flight across barriers behind a counted vmcnt.
-//
-// Schedule of K-tile t (buffer t & 1), wave (wr, wc): A half wr, B half wc >> 1, columns 64 (wc & 1) .. +63
-//   L1  read A rows 0-63 (8) + B cols 0-31 (4)     C1  acc[0..3][0..1], DMA A0(t+1) between the MFMAs
-//   L2  read B cols 32-63 (4)                      C2  acc[0..3][2..3], DMA A1(t+1)
-//   L3  read A rows 64-127 (8)                     C3  acc[4..7][2..3], DMA B0(t+2)
-//   L4  vmcnt: K-tile t+1 landed                   C4  acc[4..7][0..1], DMA B1(t+2)   (B cols 0-31 kept in registers)
-// Hazards, counted in sections (a wave of the late group runs section s one barrier interval after the early group):
-//   RAW  every wave retires its own pieces of K-tile t+1 with the vmcnt of L4(t); the first read of that buffer is in
-//        L1(t+1), two sections later, i.e. behind a barrier that every wave passed after its wait.
-//   WAR  a half-tile is re-filled two or more sections after the section that read it last, and every LOAD section drains
-//        its own ds_reads (lgkmcnt(0)) in front of its closing barrier: B halves are read last in L2 and re-filled from
-//        C3 on, A halves are read last in L3 and re-filled in C1 / C2 of the next K-tile.
-// =====================================================================================
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ILVLM_SECTION_END()                                     \
-    do {                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-        __builtin_amdgcn_sched_barrier(0);                      \
-        __builtin_amdgcn_s_barrier();                           \
-        __builtin_amdgcn_sched_barrier(0);                      \
-    } while (0)
-
-template <bool TA, bool TB, bool ACC, int PB>
-struct P8Tile {
-    typedef DmaOperand<TA, 128, 512, 64> OpA;
-    typedef DmaOperand<TB, 128, 512, 64> OpB;
-    static constexpr int HALF = 16384, BUF = 65536;
-
-    // 16 MFMAs of one quadrant; the DMA of one half-tile is issued between them (an LDS-DMA instruction costs the issuing
-    // wave 100-185 cycles next to LDS reads but ~60 among MFMAs, which keep executing while it issues)
-    template <class Op>
-    static __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const int i0, const int j0, bf16x8 (&fa)[4][2],
-                                                    bf16x8 (&fb)[2][2], bool dma, const Op& op, int tile_t,
-                                                    unsigned char* dst, int wave, int extra) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[i0 + i][j0 + j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (dma) op.issue(tile_t, dst, wave, extra);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][1], acc[i0 + i][j0 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    }
-
-    // one K-tile (t = index within this workgroup's K range, nt = their number)
-    static __device__ __forceinline__ void run(unsigned char* smem, const OpA& opa, const OpB& opb, int a_half, int b_half,
-                                               int t, int nt, int t_begin, int wave, int wr, int wc, int lane,
-                                               f32x4 (&acc)[8][4], f32x4 (&accb)[2], bool rowsum) {
-        unsigned char* cur = smem + PB * BUF;
-        unsigned char* nxt = smem + (PB ^ 1) * BUF;
-        const unsigned char* aT = cur + wr * HALF;
-        const unsigned char* bT = cur + 2 * HALF + (wc >> 1) * HALF;
-        const int bcol = (wc & 1) * 64;
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-        bf16x8 fa[4][2], fbl[2][2], fbr[2][2];
-#define P8_FRAG(TR, tile, r16, k32) p8_frag<TR, 128, 64>(tile, r16, k32, lane)
-        // ---- L1
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbl[j][ks] = P8_FRAG(TB, bT, bcol + j * 16, ks * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, i * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C1
-        quadrant(acc, 0, 0, fa, fbl, more1, opa, t_begin + t + 1, nxt, wave, 0);
-        if (ACC && rowsum) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
-                accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[0], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L2
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fbr[j][ks] = P8_FRAG(TB, bT, bcol + 32 + j * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C2
-        quadrant(acc, 0, 2, fa, fbr, more1, opa, t_begin + t + 1, nxt + HALF, wave, a_half);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L3
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = P8_FRAG(TA, aT, 64 + i * 16, ks * 32);
-        ILVLM_SECTION_END();
-        // ---- C3
-        quadrant(acc, 4, 2, fa, fbr, more2, opb, t_begin + t + 2, cur + 2 * HALF, wave, 0);
-        if (ACC && rowsum) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 s = wc == 0 ? fa[0][ks] : wc == 1 ? fa[1][ks] : wc == 2 ? fa[2][ks] : fa[3][ks];
-                accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s, accb[1], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- L4: every piece of K-tile t+1 this wave issued has landed (B0(t+2), issued in C3, may still be in flight)
-        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OpB::NLOAD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ILVLM_SECTION_END();
-        // ---- C4
-        quadrant(acc, 4, 0, fa, fbl, more2, opb, t_begin + t + 2, cur + 3 * HALF, wave, b_half);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
-
-#endif
-
-template <bool TA, bool TB, bool ACC>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B,
-                                                              int ldb, int K, int tiles_m, int tiles_n, int split_k,
-                                                              EpiArgs ep) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef DmaOperand<TA, 128, 512, 64> OpA;
-    typedef DmaOperand<TB, 128, 512, 64> OpB;
-    constexpr int HALF = 16384;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int nwg = tiles_m * tiles_n * split_k;
-    int wg = xcd_remap(blockIdx.x, nwg);
-    const int tn = wg % tiles_n; wg /= tiles_n;
-    int z, tm;
-    if (ACC) { tm = wg % tiles_m; z = wg / tiles_m; }       // K-slice major (see gemm_bf16_dma_kernel)
-    else { z = wg % split_k; tm = wg / split_k; }
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nt_total = (K + 63) / 64;
-    const int per = (nt_total + split_k - 1) / split_k;
-    const int t_begin = z * per, t_end = min(nt_total, t_begin + per);
-    if (t_begin >= t_end) return;
-    const int nt = t_end - t_begin;
-
-    OpA opa; OpB opb;
-    opa.init(A, lda, m0, ep.M, K, wave, lane);
-    opb.init(B, ldb, n0, ep.N, K, wave, lane);
-    const int a_half = TA ? 256 : 128 * lda * 2;      // byte offset of operand rows 128.. within the tile
-    const int b_half = TB ? 256 : 128 * ldb * 2;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    f32x4 accb[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
-    const bool rowsum = ACC && ep.e.a_rowsum != nullptr && tn == 0;
-
-    // prologue: K-tile 0 complete, B halves of K-tile 1
-    opa.issue(t_begin, smem_raw, wave, 0);
-    opa.issue(t_begin, smem_raw + HALF, wave, a_half);
-    opb.issue(t_begin, smem_raw + 2 * HALF, wave, 0);
-    opb.issue(t_begin, smem_raw + 3 * HALF, wave, b_half);
-    if (nt > 1) {
-        opb.issue(t_begin + 1, smem_raw + 65536 + 2 * HALF, wave, 0);
-        opb.issue(t_begin + 1, smem_raw + 65536 + 3 * HALF, wave, b_half);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OpB::NLOAD) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) {                                     // the second wave of every SIMD runs one section behind
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int t = 0; t < nt; t += 2) {
-        P8Tile<TA, TB, ACC, 0>::run(smem_raw, opa, opb, a_half, b_half, t, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
-        if (t + 1 < nt)
-            P8Tile<TA, TB, ACC, 1>::run(smem_raw, opa, opb, a_half, b_half, t + 1, nt, t_begin, wave, wr, wc, lane, acc, accb, rowsum);
-    }
-    if (wr == 0) {
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    float alpha = ep.e.alpha;
-    if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
-    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
-    __syncthreads();            // every wave is done with the operand tiles before the fragments go through the same LDS
-    if (!ACC) {
-        epilogue_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
-    } else {
-        epilogue_acc_tile<8, 4>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
-        if (rowsum && lane < 16) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = mw + (h * 4 + wc) * 16 + lane;
-                if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[h][0]);
-            }
-        }
-    }
-#endif
-}
-
-// =====================================================================================
 // bf16 "streaming" kernel (round 3): store-type GEMMs C[M,N] = A[M,K] . Bop[N,K]^T whose B operand is a WEIGHT, i.e. can be
 // kept pre-packed in MFMA fragment order (ilvlm_gemm_pack_b): the forward products and input gradients of the towers.
 //
@@ -1851,20 +1608,6 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <bool TA, bool TB, bool ACC>
-int launch_p8(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    auto kern = gemm_bf16_p8_kernel<TA, TB, ACC>;
-    constexpr int bytes = 131072;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
-    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_p8: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
-    hipLaunchKernelGGL(kern, dim3(tm * tn * split_k), dim3(512), bytes, s, A, lda, B, ldb, K, tm, tn, split_k, ep);
-    ILVLM_LAUNCH_CHECK("gemm_bf16_p8");
-    return ILVLM_OK;
-}
-
 template <int WN>
 int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
     constexpr int ring = 3 * 128 * 64 * 2, epi = WN * 8192;
@@ -1900,6 +1643,11 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 //                  for production through ILVLM_PK_SPLITK -- measured slower on the step's shapes);
 //    5           = always the single-stage direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
 //    0           = the register-staged general kernel only.
+// (Round 3 re-ran round 2's 256x256 phased 8-wave kernel on the inline-asm DMA, i.e. for the first time with loads that stay in
+// flight across its barriers: 1180 TFLOP/s at 4096^3 against 1057 for the streaming kernel and 913 for the 128x128 one -- and
+// 7..20 % SLOWER than the streaming kernel on every shape of the ViT-B/32 step (12 K-tiles, 150..600 tiles for 256 CUs) and of
+// ViT-L/14 (516 tiles = 2.02 rounds); profiles/round3/gemm_bench_phased_asm_dma.txt, gemm_bench_vitl14_phased.txt.  It is the
+// commit before this one in the git history.)
 // The tilings and pipelines that rounds 1 and 2 measured and lost with (64x128, 256x128 3-stage, 256x256 phased, stream-K,
 // persistent, 2-/3-deep rings, 128-deep K-tiles) live in the git history; DESIGN.md section 6 has their numbers.
 std::atomic<int> g_gemm_variant{15};
@@ -2049,16 +1797,6 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             if (wn == 4) return launch_pk<4>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
             return launch_pk<2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
         }
-        if (fast && variant == 8 && M >= 256 && N >= 256) {      // 256x256 phased kernel (A/B selector only)
-#define ILVLM_P8(TA, TB)                                                                                 \
-    return swap ? launch_p8<TA, TB, false>(a, lda, b, ldb, K, M, N, split_k, ep, s)                      \
-                : launch_p8<TA, TB, true>(a, lda, b, ldb, K, M, N, split_k, ep, s)
-            if (!trans_a && !trans_b) { ILVLM_P8(false, false); }
-            if (!trans_a && trans_b) { ILVLM_P8(false, true); }
-            if (trans_a && !trans_b) { ILVLM_P8(true, false); }
-            ILVLM_P8(true, true);
-#undef ILVLM_P8
-        }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU
             if (!swap) slab_setup(64);
@@ -2109,7 +1847,7 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || variant == 5 || variant == 8 || (variant >= 15 && variant <= 17), "gemm_set_variant: 0, 5, 8, 15, 16 or 17");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || (variant >= 15 && variant <= 17), "gemm_set_variant: 0, 5, 15, 16 or 17");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
     return ILVLM_OK;
 }
