@@ -92,55 +92,7 @@ def run_grouped(rounds=7, targets=(512,)):
               "  ".join("%s %6.1f us %6.1f TF/s" % (m, t * 1e3, fl / (t * 1e-3) / 1e12) for m, t in best.items()), flush=True)
 
 
-def run_pairs(rounds=7):
-    """store-type products of the two towers that are ready together: two launches (back to back on one stream, and on two
-    streams) against ONE grouped launch (ops.gemm_group)"""
-    torch.manual_seed(0)
-    flush = torch.empty(128 * 1024 * 1024, device="cuda")
-    side = torch.cuda.Stream()
-    tot = {}
-    for name, (nv, kv), (nt_, kt) in (("qkv.fwd", (2304, 768), (1536, 512)), ("out.fwd", (768, 768), (512, 512)),
-                                      ("fc.fwd", (3072, 768), (2048, 512)), ("proj.fwd", (768, 3072), (512, 2048)),
-                                      ("qkv.dgrad", (768, 2304), (512, 1536)), ("out.dgrad", (768, 768), (512, 512)),
-                                      ("fc.dgrad", (768, 3072), (512, 2048)), ("proj.dgrad", (3072, 768), (2048, 512))):
-        probs = []
-        for m, n, k in ((12800, nv, kv), (11319, nt_, kt)):
-            a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
-            w = torch.randn(n, k, device="cuda").to(torch.bfloat16)
-            probs.append(dict(a=a, w=w, b_packed=ops.gemm_pack_b(w), out=torch.empty(m, n, dtype=torch.bfloat16, device="cuda")))
-        best = {}
-        for r in range(rounds + 1):
-            for mode in ("one stream", "two streams", "grouped"):
-                flush.zero_()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                if mode == "grouped":
-                    ops.gemm_group(probs)
-                elif mode == "one stream":
-                    for p in probs:
-                        ops.gemm(p["a"], p["w"], p["out"], b_packed=p["b_packed"])
-                else:
-                    side.wait_stream(torch.cuda.current_stream())
-                    ops.gemm(probs[0]["a"], probs[0]["w"], probs[0]["out"], b_packed=probs[0]["b_packed"])
-                    with torch.cuda.stream(side):
-                        ops.gemm(probs[1]["a"], probs[1]["w"], probs[1]["out"], b_packed=probs[1]["b_packed"])
-                    torch.cuda.current_stream().wait_stream(side)
-                e1.record()
-                torch.cuda.synchronize()
-                if r:
-                    best[mode] = min(best.get(mode, 1e9), e0.elapsed_time(e1))
-        for m_, t in best.items():
-            tot[m_] = tot.get(m_, 0.0) + t
-        print("%-11s ViT N=%4d K=%4d + text N=%4d K=%4d: " % (name, nv, kv, nt_, kt) +
-              "  ".join("%s %6.1f us" % (m_, t * 1e3) for m_, t in best.items()), flush=True)
-    print("sum: " + "  ".join("%s %6.1f us" % (m_, t * 1e3) for m_, t in tot.items()))
-
-
 if __name__ == "__main__":
-    if "--pairs" in sys.argv:
-        run_pairs()
-        sys.exit(0)
     if "--grouped" in sys.argv:
         run_grouped()
         sys.exit(0)

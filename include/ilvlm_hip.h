@@ -138,20 +138,6 @@ int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int ldb, void* p
  * per 64 x 64 tile of a weight (rows, cols and the offset multiples of 64).  fwd (same offsets) receives the trans_b = 0
  * image of W (the forward product X W^T), bwd the trans_b = 1 image (the input gradient dY W). */
 int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, const int32_t* table, int n_tiles, void* stream);
-/* Grouped store-type products: `count` independent C_p[m_p, n_p] = A_p[m_p, k_p] . Bop_p^T (+ each problem's own epilogue) as
- * ONE launch of the streaming kernel over the concatenated tile lists -- nn.Linear forward products / input gradients of
- * DIFFERENT modules that are ready together (the ViT block's and the text block's out-projection, base_transformer.py:35-48 of
- * both towers), so that rounds of workgroups fill.  Every problem: bf16, A row-major K-contiguous, epi.b_packed required
- * (B / ldb of ilvlm_gemm are not taken), K % 64 == 0, N % 256 == 0, no accumulate / pool / rowbias / out_group; results are
- * bit-identical to `count` ilvlm_gemm calls. */
-#define ILVLM_GEMM_GROUP_MAX 2
-typedef struct ilvlm_gemm_problem {
-    const void* a;
-    void* c;
-    int m, n, k, lda, ldc;
-    ilvlm_gemm_epilogue epi;
-} ilvlm_gemm_problem;
-int ilvlm_gemm_group(const ilvlm_gemm_problem* problems, int count, void* stream);
 /* Grouped weight gradients: gw_p[n_p, k_p] += dy_p^T x_p (and gb_p[n_p] += column sums of dy_p) for `count` nn.Linear layers
  * that share their token rows -- the four linears of one residual attention block (autograd of F.linear at
  * image_encoder/base_transformer.py:35-41,45-48; text twin text_encoder/base_transformer.py:33-48) -- as ONE launch over the

@@ -1226,11 +1226,9 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned
 // SK: compiled with the store-type split-K hand-off (a separate instantiation: its slab reduction raises the register
 // allocation from ~200 to 256 per lane, which at two waves per SIMD would leave no room for a co-resident wave of another
 // kernel -- and the step runs four streams).
-// (body shared by the single-problem kernel and the grouped one, pk_group_kernel: `wg_linear` is the workgroup's index
-// within ITS problem, already passed through xcd_remap)
 template <int WN, bool SK>
-__device__ __forceinline__ void pk_gemm_body(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp, int K, int tiles_m,
-                                             int tiles_n, int split_k, const EpiArgs& ep, int wg_linear) {
+__global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
+                                                                  int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
     constexpr int STAGE = 128 * 64 * 2;
@@ -1238,7 +1236,7 @@ __device__ __forceinline__ void pk_gemm_body(const bf16* __restrict__ A, int lda
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the K-slices of a tile are neighbours in the linear order: they run at the same time, on the same XCD
-    int wg = wg_linear;
+    int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n * split_k);
     const int zs = wg % split_k;
     wg /= split_k;
     const int tile_id = wg;
@@ -1436,35 +1434,6 @@ __device__ __forceinline__ void pk_gemm_body(const bf16* __restrict__ A, int lda
     }
 #endif
 #endif
-}
-
-template <int WN, bool SK>
-__global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
-                                                                  int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
-    pk_gemm_body<WN, SK>(A, lda, Bp, K, tiles_m, tiles_n, split_k, ep, xcd_remap(blockIdx.x, tiles_m * tiles_n * split_k));
-}
-
-// Grouped store-type products (ilvlm_gemm_group): independent C_p = A_p . Bop_p^T with their own shapes and epilogues as ONE
-// launch of the streaming kernel over the concatenated tile lists -- the ViT block's and the text block's out-projection
-// (300 + 178 tiles of 128 x 256: one full round of the 512 workgroup slots instead of two under-filled launches).
-struct PkProblem {
-    const bf16* A;
-    const bf16* Bp;
-    int lda, K, tiles_m, tiles_n, wg_begin, pad_;
-    EpiArgs ep;
-};
-struct PkGroupArgs {
-    PkProblem p[ILVLM_GEMM_GROUP_MAX];
-    int count, total;
-};
-__global__ __launch_bounds__(256, 2) void pk_group_kernel(PkGroupArgs g) {
-    const int wg = xcd_remap(blockIdx.x, g.total);
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < ILVLM_GEMM_GROUP_MAX; ++i)
-        if (i < g.count && wg >= g.p[i].wg_begin) pi = i;
-    const PkProblem& P = g.p[pi];
-    pk_gemm_body<4, false>(P.A, P.lda, P.Bp, P.K, P.tiles_m, P.tiles_n, 1, P.ep, wg - P.wg_begin);
 }
 
 // packed copy of one B operand (ilvlm_gemm_pack_b): one thread per 16-byte chunk
@@ -1899,57 +1868,6 @@ extern "C" int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, 
     hipLaunchKernelGGL(pack_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)arena_bf16, (bf16*)fwd,
                        (bf16*)bwd, table);
     ILVLM_LAUNCH_CHECK("pack_weights");
-    return ILVLM_OK;
-}
-
-extern "C" int ilvlm_gemm_group(const ilvlm_gemm_problem* problems, int count, void* stream) {
-    ILVLM_REQUIRE(problems && count >= 1 && count <= ILVLM_GEMM_GROUP_MAX, "gemm_group: 1..%d problems", ILVLM_GEMM_GROUP_MAX);
-    PkGroupArgs g = {};
-    g.count = count;
-    int total = 0;
-    static const int tile_group_env = getenv("ILVLM_GEMM_TILE_GROUP") ? atoi(getenv("ILVLM_GEMM_TILE_GROUP")) : 4;
-    static const int tile_kmax_env = getenv("ILVLM_GEMM_TILE_KMAX") ? atoi(getenv("ILVLM_GEMM_TILE_KMAX")) : 1024;
-    static const int tile_bands_env = getenv("ILVLM_GEMM_TILE_BANDS") ? atoi(getenv("ILVLM_GEMM_TILE_BANDS")) : 8;
-    for (int i = 0; i < count; ++i) {
-        const ilvlm_gemm_problem& q = problems[i];
-        const ilvlm_gemm_epilogue& e = q.epi;
-        ILVLM_REQUIRE(q.a && e.b_packed && (q.c || (e.out8 && !e.pool_out)) && q.m > 0 && q.n > 0 && q.k > 0, "gemm_group: problem %d: null pointer / bad shape", i);
-        ILVLM_REQUIRE(q.k % 64 == 0 && q.n % 256 == 0 && q.lda >= q.k && q.lda % 8 == 0 && q.ldc >= q.n, "gemm_group: problem %d: K %% 64 == 0, N %% 256 == 0, lda >= K, ldc >= N", i);
-        ILVLM_REQUIRE(!e.accumulate && !e.pool_out && !e.a_rowsum, "gemm_group: problem %d: store-type products only", i);
-        ILVLM_REQUIRE(aligned(q.a, 16) && aligned(e.b_packed, 16) && (long)q.n * q.k * 2 < (1L << 31), "gemm_group: problem %d: operand alignment / size", i);
-        ILVLM_REQUIRE(!(e.act && !e.aux) && e.act >= 0 && e.act <= ILVLM_ACT_GELU_ERF_BWD && e.out_group == 0 && !e.rowbias, "gemm_group: problem %d: epilogue", i);
-        ILVLM_REQUIRE(e.out_dtype == ILVLM_F32 || e.out_dtype == ILVLM_BF16, "gemm_group: problem %d: bad out_dtype", i);
-        PkProblem& P = g.p[i];
-        P.A = (const bf16*)q.a;
-        P.Bp = (const bf16*)e.b_packed;
-        P.lda = q.lda;
-        P.K = q.k;
-        P.tiles_m = ceil_div(q.m, 128);
-        P.tiles_n = q.n / 256;
-        P.wg_begin = total;
-        total += P.tiles_m * P.tiles_n;
-        P.ep.e = e;
-        P.ep.e.splitk_ws = nullptr;
-        P.ep.Cf = (float*)q.c;
-        P.ep.Cb = (bf16*)q.c;
-        P.ep.ldc = q.ldc;
-        P.ep.M = q.m;
-        P.ep.N = q.n;
-        const size_t caln = e.out_dtype == ILVLM_F32 ? 16 : 8;
-        P.ep.vec_ok = (q.n % 4 == 0) && (q.ldc % 4 == 0) && aligned(q.c, caln) && (!e.bias || aligned(e.bias, 16)) &&
-                      (!e.residual || aligned(e.residual, 16)) && (!e.aux || aligned(e.aux, 8));
-        P.ep.tile_group = (tile_group_env > 0 && q.k <= tile_kmax_env && P.tiles_n > tile_group_env) ? tile_group_env : 0;
-        P.ep.tile_bands = tile_bands_env;
-        P.ep.plain_acc = 0;
-    }
-    g.total = total;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    constexpr int bytes = 3 * 128 * 64 * 2;
-    std::call_once(once, [&] { attr_err = hipFuncSetAttribute((const void*)pk_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
-    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_group: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    hipLaunchKernelGGL(pk_group_kernel, dim3(total), dim3(256), bytes, (hipStream_t)stream, g);
-    ILVLM_LAUNCH_CHECK("gemm_group");
     return ILVLM_OK;
 }
 

@@ -36,14 +36,6 @@ class Block(C.Structure):
                 [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")])
 
 
-class GemmProblem(C.Structure):
-    """ilvlm_gemm_problem: one store-type product of a grouped streaming launch (ilvlm_gemm_group)"""
-    _fields_ = [("a", vp), ("c", vp), ("m", i32), ("n", i32), ("k", i32), ("lda", i32), ("ldc", i32), ("epi", GemmEpilogue)]
-
-
-GEMM_GROUP_MAX = 2
-
-
 class WgradProblem(C.Structure):
     """ilvlm_wgrad_problem: one gw[n, k] += dy^T x (gb[n] += column sums of dy) of a grouped weight-gradient launch"""
     _fields_ = [("dy", vp), ("x", vp), ("gw", vp), ("gb", vp), ("n", i32), ("k", i32), ("inv_g", vp), ("inv_x", vp)]
@@ -64,7 +56,6 @@ SIGNATURES = {
     "ilvlm_gemm_pack_b": [i32, i32, i32, vp, i32, vp, vp],
     "ilvlm_pack_weights": [vp, vp, vp, vp, i32, vp],
     "ilvlm_wgrad_group": [i32, C.POINTER(WgradProblem), i32, i64, i32, vp],
-    "ilvlm_gemm_group": [C.POINTER(GemmProblem), i32, vp],
     "ilvlm_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp],
     "ilvlm_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "ilvlm_layernorm_fwd_q8": [vp, i32, vp, vp, vp, i32, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp, vp],

@@ -284,35 +284,6 @@ def pack_weights(arena_bf16, fwd, bwd, table):
                                         _stream()), "pack_weights")
 
 
-def gemm_group(problems):
-    """ONE streaming-kernel launch for up to two independent store-type bf16 products (ilvlm_gemm_group).  problems: list of
-    dict(a=[m,k] bf16, b_packed=packed [n,k] weights, out=[m,n], bias=, residual=, aux=, act=); results are bit-identical
-    to one gemm(..., b_packed=...) call per problem."""
-    if not 1 <= len(problems) <= L.GEMM_GROUP_MAX:
-        raise RuntimeError("gemm_group: 1..%d problems" % L.GEMM_GROUP_MAX)
-    arr = (L.GemmProblem * len(problems))()
-    for i, pr in enumerate(problems):
-        a, out, bp = pr["a"], pr["out"], pr["b_packed"]
-        _chk(a, "gemm_group.a", torch.bfloat16); _chk(out, "gemm_group.out"); _chk(bp, "gemm_group.b_packed", torch.bfloat16)
-        m, k = a.shape
-        n = out.shape[1]
-        if out.shape[0] != m or bp.numel() != n * k:
-            raise RuntimeError("gemm_group: problem %d: a %s, out %s, b_packed %d elements" % (i, tuple(a.shape), tuple(out.shape), bp.numel()))
-        bias, residual, aux = pr.get("bias"), pr.get("residual"), pr.get("aux")
-        if bias is not None:
-            _chk(bias, "gemm_group.bias", torch.float32, (n,))
-        if residual is not None:
-            _chk(residual, "gemm_group.residual", torch.float32, out.shape)
-        if aux is not None:
-            _chk(aux, "gemm_group.aux", torch.bfloat16, (m, n))
-        epi = GemmEpilogue(_p(bias), None, _p(residual), _p(aux), None, 1.0, int(pr.get("act", 0)), dt(out), 0, 0, 0, None)
-        epi.b_packed = bp.data_ptr()
-        arr[i].a, arr[i].c = a.data_ptr(), out.data_ptr()
-        arr[i].m, arr[i].n, arr[i].k, arr[i].lda, arr[i].ldc = m, n, k, a.stride(0), out.stride(0)
-        arr[i].epi = epi
-    L.check(L.load().ilvlm_gemm_group(arr, len(problems), _stream()), "gemm_group")
-
-
 _WGRAD_GROUP_SLOTS = int(os.environ.get("ILVLM_WGRAD_GROUP_SLOTS", "512"))
 
 

@@ -824,40 +824,6 @@ def test_slab_split_k_weight_gradient_is_right_and_bit_reproducible(M, N, K, spl
     assert int(slab[1].abs().sum()) == 0                 # every ticket counter is back at zero
 
 
-def test_grouped_streaming_gemm_equals_single_launches():
-    """ilvlm_gemm_group: two independent store-type products (the two towers' out-projections / down-projections, with their own
-    shapes and epilogues) as ONE launch of the streaming kernel: bit-identical to one ilvlm_gemm call each, also for a single
-    problem and for ragged row counts; shapes the kernel cannot take are refused"""
-    ops = _ops()
-    cases = [((12800, 768, 768), (11319, 512, 512)), ((12800, 768, 3072), (11319, 512, 2048)), ((1000, 256, 128), (77, 512, 64)),
-             ((12800, 3072, 768),)]
-    for case in cases:
-        probs, want = [], []
-        for i, (m, n, k) in enumerate(case):
-            a = rnd(m, k, seed=1 + i).to(torch.bfloat16).cuda()
-            w = rnd(n, k, seed=5 + i).to(torch.bfloat16).cuda()
-            bp = ops.gemm_pack_b(w)
-            bias = rnd(n, seed=9 + i).cuda()
-            res = rnd(m, n, seed=13 + i).cuda() if i == 0 else None
-            aux = torch.empty(m, n, dtype=torch.bfloat16, device="cuda") if i == 1 else None
-            out = torch.empty(m, n, dtype=torch.float32 if i == 0 else torch.bfloat16, device="cuda")
-            probs.append(dict(a=a, b_packed=bp, out=out, bias=bias, residual=res, aux=aux, act=1 if i == 1 else 0))
-            ref = torch.empty_like(out)
-            raux = torch.empty_like(aux) if aux is not None else None
-            ops.gemm(a, w, ref, bias=bias, residual=res, aux=raux, act=1 if i == 1 else 0, b_packed=bp)
-            want.append((ref, raux))
-        ops.gemm_group(probs)
-        for pr, (ref, raux) in zip(probs, want):
-            assert torch.equal(pr["out"], ref)
-            if raux is not None:
-                assert torch.equal(pr["aux"], raux)
-    a = rnd(256, 64, seed=1).to(torch.bfloat16).cuda()
-    w = rnd(200, 64, seed=2).to(torch.bfloat16).cuda()          # N not a multiple of 256
-    with pytest.raises(RuntimeError):
-        ops.gemm_group([dict(a=a, b_packed=torch.empty(200 * 64, dtype=torch.bfloat16, device="cuda"),
-                             out=torch.empty(256, 200, dtype=torch.bfloat16, device="cuda"))])
-
-
 @pytest.mark.parametrize("rows,E,target", [(12800, 768, 512), (11319, 512, 512), (11319, 512, 2000), (1000, 192, 512), (77, 64, 512)])
 def test_grouped_weight_gradients(rows, E, target):
     """the four weight gradients of a block as ONE launch (ilvlm_wgrad_group): every product and bias gradient equal to the
