@@ -446,6 +446,26 @@ def test_colsum_cast_scale():
     assert rel(y, src * 0.25) == 0.0
 
 
+@pytest.mark.parametrize("n,max_norm", [(1, 0.5), (1000, 3.0), (4 * 1024 * 1024 + 37, 10.0), (50000, 1e9)])
+def test_clip_grad_norm_over_a_flat_buffer(n, max_norm):
+    """ilvlm_sumsq + ilvlm_clip_by_norm = clip_grad_norm_ of the reference (prototype/utils/grad_clip.py:12-47) over one flat
+    gradient buffer: the squared norm on the device, the buffer scaled by max_norm / (norm + 1e-6) only when that is below 1"""
+    ops = _ops()
+    g = rnd(n, seed=3).cuda() * 2.5
+    raw = g.clone()
+    ss = ops.clip_grad_norm_(g, max_norm)
+    tn = torch.linalg.vector_norm(raw.double())
+    assert abs(float(ss) - float(tn) ** 2) <= 1e-4 * float(tn) ** 2
+    coef = max_norm / (float(tn) + 1e-6)
+    if coef < 1:
+        assert float((g - raw * coef).abs().max()) <= 1e-5 * float(raw.abs().max())
+    else:
+        assert torch.equal(g, raw)
+    scratch = torch.full((1,), 123.0, device="cuda")             # a caller-provided accumulator is zeroed first
+    ss2 = ops.clip_grad_norm_(raw.clone(), max_norm, scratch)
+    assert ss2.data_ptr() == scratch.data_ptr() and abs(float(ss2) - float(tn) ** 2) <= 1e-4 * float(tn) ** 2
+
+
 def test_adamw_matches_torch():
     import ctypes as C
     from ilvlm_amd import lib as L
