@@ -141,14 +141,23 @@ struct WgradBatch {
     long rows = 0;
 };
 
+// wg waits for everything enqueued on s so far.  The events come from a small per-thread ring that is never destroyed: an
+// event recorded while a stream is being captured into a hipGraph must outlive the capture (destroying it right after the
+// wait, as this code did, crashed hipStreamEndCapture), and a ring also saves a create / destroy pair per call.  Re-recording
+// an event that an earlier wait still refers to is safe: a wait binds to the record that preceded it.
 int order_after(hipStream_t s, hipStream_t wg) {
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: hipEventCreate: %s", hipGetErrorString(e));
-    e = hipEventRecord(ev, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(wg, ev, 0);
-    hipError_t e2 = hipEventDestroy(ev);       // destruction is deferred until the event has completed
-    if (e == hipSuccess) e = e2;
+    constexpr int RING = 64;
+    static thread_local hipEvent_t ring[RING];
+    static thread_local int filled = 0, next = 0;
+    if (filled < RING) {
+        hipError_t e = hipEventCreateWithFlags(&ring[filled], hipEventDisableTiming);
+        if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: hipEventCreate: %s", hipGetErrorString(e));
+        next = filled++;
+    } else {
+        next = (next + 1) % RING;
+    }
+    hipError_t e = hipEventRecord(ring[next], s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(wg, ring[next], 0);
     if (e != hipSuccess) ILVLM_FAIL((int)e, "block_bwd: stream ordering: %s", hipGetErrorString(e));
     return ILVLM_OK;
 }
