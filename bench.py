@@ -353,7 +353,7 @@ def main():
                                            "output + epilogue operands once each, from the launches timed here" % traffic_src,
                             algorithmic_bytes_per_launch=round(s["bytes"] / max(s["launches"], 1)),
                             kernel="gemm_bf16_pk_kernel + gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step: the streaming "
-                                   "kernel on fragment-packed weights for forward / input gradients with K >= 768, the "
+                                   "kernel on fragment-packed weights for forward / input gradients with K >= 512, the "
                                    "direct-to-LDS kernels for the rest and the weight gradients); achieved = their FLOPs / the "
                                    "sum of their durations with the towers serialised (HIP events on the launch stream)",
                             launches_per_step=s["launches"] // nprof,

@@ -122,7 +122,7 @@ typedef struct ilvlm_gemm_epilogue {
 int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda,
                const void* B, int ldb, void* C, int ldc, const ilvlm_gemm_epilogue* epi, int split_k, void* stream);
 /* bf16 kernel selection (tuning / tests; process-wide atomic): 15 (default) the streaming kernel where the epilogue offers
- * b_packed and the K-loop is long enough to pay (K >= 768), the two-stage direct-to-LDS kernel for weight gradients and the
+ * b_packed and K >= 512 (ILVLM_PK_MIN_K), the two-stage direct-to-LDS kernel for weight gradients and the
  * single-stage direct-to-LDS 128x128 kernel elsewhere; 16 as 15 but the streaming kernel for every eligible shape (tests);
  * 17 as 16 plus store-type split-K with an in-launch slab reduction where splitk_ws / splitk_cnt are offered (tests);
  * 5 always the single-stage direct-to-LDS 128x128 kernel (the A/B reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged

@@ -1761,10 +1761,10 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         const bool fast = (variant != 0 || epi->pool_out) && (K % BK == 0 || (trans_a && trans_b)) && (!trans_a || (M % 8 == 0 && M >= 8)) &&
                           (!trans_b || (N % 8 == 0 && N >= 8));
         // streaming kernel: the caller offers B in fragment order (weights); A must be K-contiguous, whole K-tiles
-        // Per-shape choice, measured cold-cache per launch (benchmarks/gemm_bench.py, profiles/round3/gemm_bench.txt): the
-        // streaming kernel wins where the K-loop is long enough to amortise its two-deep prologue (K >= 768: +5..11 % on the
-        // ViT-B/32 shapes with 128x256 tiles) and loses 7..12 % on the K = 512 shapes of the text tower (8 K-tiles), which
-        // keep the direct-to-LDS kernel.
+        // Per-shape choice (benchmarks/gemm_bench.py, profiles/round3/gemm_bench.txt): alone and cold-cache the streaming kernel
+        // wins +5..11 % on the K >= 768 shapes of ViT-B/32 and loses 2..8 % on three of the K = 512 shapes of the text tower
+        // (8 K-tiles: its two-deep prologue weighs more); inside the step the K = 512 shapes are 0.3 % better on it too (fewer
+        // kernels competing for LDS), hence the threshold of 512.
         static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 512;
         if ((variant >= 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
             (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
