@@ -687,6 +687,9 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
 }
 #endif
 
+#ifndef ILVLM_PK_PRIO
+#define ILVLM_PK_PRIO 1               // wave priority of the streaming kernel (see gemm_bf16_pk_kernel)
+#endif
 #ifndef ILVLM_FP8_SCALED_MFMA
 #define ILVLM_FP8_SCALED_MFMA 1      // K-contiguous fp8 operands (forward, input gradient): -9 % GEMM time, fp8 step +3.9 %
 #endif
@@ -1232,6 +1235,10 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
     constexpr int STAGE = 128 * 64 * 2;
+    // The forward / input-gradient chain is what the step waits for; the weight gradients that share its SIMDs (one streaming
+    // wave + one weight-gradient wave is the common pairing at 221 + 151 VGPRs) are not.  Wave priority 1: 17.005 -> 16.94 ms,
+    // same box, two pairs (priority 3: the same).  -DILVLM_PK_PRIO=0 for the A/B.
+    __builtin_amdgcn_s_setprio(ILVLM_PK_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
