@@ -1,14 +1,36 @@
 """Micro-benchmark of the bf16 GEMM kernels on the shapes of one ViT-B/32 + text block at per-GPU batch 256
 (forward, dgrad, wgrad).  Interleaved rounds in one process, cold caches (a 512 MB write between launches, as inside a
 train step); prints TFLOP/s per shape for selector 5 (direct-to-LDS single-stage kernel everywhere) and 15 (default: the
-streaming kernel on a packed B operand for the store-type shapes, the two-stage ring for the weight gradients).  usage: gemm_bench.py [tag-substring] [--epi] [--wn 2|4 via ILVLM_PK_WN]"""
+streaming kernel on a packed B operand for the store-type shapes, the two-stage ring for the weight gradients).  Round 4:
+GEMM_BENCH_VARIANTS=19,15 times the one-tile streaming kernel (19) against the persistent one (15, the default; 18 = persistent
+for every eligible shape).  usage: gemm_bench.py [tag-substring] [--epi] [--wn 2|4 via ILVLM_PK_WN]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ilvlm_amd import ops
 
-# selectors timed side by side (GEMM_BENCH_VARIANTS=5,15 by default)
-VARIANTS = tuple(int(x) for x in os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(","))
+# selectors timed side by side (GEMM_BENCH_VARIANTS=5,15 by default).  A selector may carry settings of the persistent streaming
+# kernel: "15:s1000:e2:g256" = selector 15 with a start stagger of 1000 cycles per K-tile, epilogue placement 2, 256 workgroups
+VARIANT_SPECS = os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(",")
+
+
+def _parse(spec):
+    parts = spec.split(":")
+    d = dict(v=int(parts[0]), s=-1, e=-1, g=0)
+    for q in parts[1:]:
+        d[q[0]] = int(q[1:])
+    return d
+
+
+VSET = {spec: _parse(spec) for spec in VARIANT_SPECS}
+VARIANTS = tuple(VARIANT_SPECS)
+
+
+def select(spec):
+    d = VSET[spec]
+    ops.gemm_set_variant(d["v"])
+    ops.gemm_set_persistent(d["g"], d["e"], d["s"])
+    return d["v"]
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
     for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E)):
@@ -39,25 +61,26 @@ def run(rounds=7, only=None, epi=False, sk=True):
         variants = VARIANTS
         best = {v: 1e9 for v in variants}
         for r in range(rounds + 1):
-            for v in variants:
-                ops.gemm_set_variant(v)
+            for spec in variants:
+                v = select(spec)
                 flush.zero_()            # cold caches, as inside a train step
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split,
-                         b_packed=packed if v == 15 else None, slab=slab if (v == 15 and not acc) else None, **kw)
+                         b_packed=packed if v >= 15 else None, slab=slab if (v in (15, 17) and not acc) else None, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
-                    best[v] = min(best[v], e0.elapsed_time(e1))
+                    best[spec] = min(best[spec], e0.elapsed_time(e1))
         fl = 2.0 * M * N * K
         for v in variants:
             tot[v] += best[v]
         print("%-18s M=%6d N=%5d K=%6d split=%2d  " % (tag, M, N, K, split) +
-              "  ".join("v%d %7.1f TF/s (%6.1f us)" % (v, fl / (best[v] * 1e-3) / 1e12, best[v] * 1e3) for v in variants) +
-              "   x%.2f" % (best[5] / best[15]), flush=True)
+              "  ".join("v%s %7.1f TF/s (%6.1f us)" % (v, fl / (best[v] * 1e-3) / 1e12, best[v] * 1e3) for v in variants) +
+              "   x%.2f" % (best[VARIANTS[0]] / best[VARIANTS[-1]]), flush=True)
     ops.gemm_set_variant(15)
-    print("sum of best times: " + ", ".join("v%d %.1f us" % (v, tot[v] * 1e3) for v in VARIANTS))
+    ops.gemm_set_persistent(0, -1, -1)
+    print("sum of best times: " + ", ".join("v%s %.1f us" % (v, tot[v] * 1e3) for v in VARIANTS))
 
 
 def run_grouped(rounds=7, targets=(512,)):

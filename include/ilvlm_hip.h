@@ -125,9 +125,20 @@ int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K,
  * b_packed and K >= 512 (ILVLM_PK_MIN_K), the two-stage direct-to-LDS kernel for weight gradients and the
  * single-stage direct-to-LDS 128x128 kernel elsewhere; 16 as 15 but the streaming kernel for every eligible shape (tests);
  * 17 as 16 plus store-type split-K with an in-launch slab reduction where splitk_ws / splitk_cnt are offered (tests);
+ * 18 / 19: see ilvlm_gemm_set_persistent;
  * 5 always the single-stage direct-to-LDS 128x128 kernel (the A/B reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
  * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
+/* The persistent streaming kernel (default for b_packed products with an even number of 64-deep K-tiles; selector 18 forces
+ * it for every eligible shape, 19 = selector 15 without it): `slots` workgroups per launch, each walking several output
+ * tiles with the next tile's operands in flight under the current tile's epilogue (0 = two per CU); epi_sep: where the
+ * epilogue transposes, 1 = LDS of its own behind the operand ring (80 KiB per workgroup), 0 = the ring's free stage (48 KiB),
+ * 2 = half and half (64 KiB),
+ * -1 = default (ILVLM_PKP_EPI_SEP); stagger: the second half of the grid (by dispatch order the second workgroup of each CU)
+ * starts its first tile this many shader cycles per K-tile late, so that the two workgroups of a CU alternate between
+ * multiplying and storing instead of doing both in lock-step (-1 = default / ILVLM_PKP_STAGGER, 0 = none; results do not
+ * depend on it).  Tuning / test hook, process-wide atomics. */
+int ilvlm_gemm_set_persistent(int slots, int epi_sep, int stagger);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +
@@ -317,8 +328,12 @@ int ilvlm_add_inplace(float* y, const float* x, long n, void* stream);
 int ilvlm_clamp(float* x, float lo, float hi, long n, void* stream);
 /* Gradient-norm clipping over the flat gradient arena (grad_clip.type 'norm': clip_grad_norm_, prototype/utils/grad_clip.py:12-47,
  * called at train_solver.py:403-405): out[0] += sum x^2 (zero it first), then x *= max_norm / (sqrt(sumsq[0]) + 1e-6) when that
- * factor is below 1; the norm never leaves the device. */
-int ilvlm_sumsq(const float* x, long n, float* out, void* stream);
+ * factor is below 1; the norm never leaves the device.  The sum is bitwise reproducible (its order is a function of n alone:
+ * fixed grid, one partial per workgroup into `partials` -- a caller workspace of ilvlm_sumsq_partials() floats --, added up in
+ * index order by one workgroup), so data-parallel replicas that clip the same averaged gradients stay bit-identical, as
+ * torch's clip_grad_norm_ keeps them. */
+int ilvlm_sumsq_partials(void);
+int ilvlm_sumsq(const float* x, long n, float* out, float* partials, void* stream);
 int ilvlm_clip_by_norm(float* x, long n, const float* sumsq, float max_norm, void* stream);
 
 /* ---- fused multi-tensor AdamW (torch.optim.AdamW semantics, optimizer/__init__.py:3,18-26).

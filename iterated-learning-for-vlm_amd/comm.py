@@ -27,6 +27,22 @@ import torch
 import torch.distributed as dist
 
 _FORCE = os.environ.get("ILVLM_COMM_FORCE", "0") == "1"
+_TRACE = None        # list of (op, begin, end, dtype, elements) per collective issued, in issue order (trace(True))
+
+
+def trace(on=True):
+    """Record every collective this module issues -- (op, range begin, range end, dtype, elements) in issue order -- and return
+    the list (None when switched off).  RCCL matches collectives by their ORDER on each rank: a step whose sequence differed
+    between ranks (say, because two tower streams announced their ranges in a timing-dependent order) would deadlock or mix
+    buffers at world size 8.  The sequence here is a function of the host program alone; tests compare it across ranks."""
+    global _TRACE
+    _TRACE = [] if on else None
+    return _TRACE
+
+
+def _note(op, begin, end, t):
+    if _TRACE is not None:
+        _TRACE.append((op, int(begin), int(end), str(t.dtype).replace("torch.", ""), int(t.numel())))
 
 
 def force_collectives(on):
@@ -57,6 +73,7 @@ def gather_pair(img, txt):
     B, D = img.shape
     send = torch.stack([img, txt], 0).contiguous()                  # [2,B,D]
     recv = torch.empty((W, 2, B, D), dtype=img.dtype, device=img.device)
+    _note("all_gather", 0, 0, send)
     dist.all_gather_into_tensor(recv.view(W * 2 * B, D), send.view(2 * B, D))
     return recv[:, 0].reshape(W * B, D).contiguous(), recv[:, 1].reshape(W * B, D).contiguous()
 
@@ -68,6 +85,7 @@ def reduce_gathered(dg_img, dg_txt, B):
         return dg_img, dg_txt
     D = dg_img.shape[1]
     send = torch.stack([dg_img.view(W, B, D), dg_txt.view(W, B, D)], 1).contiguous()   # [W,2,B,D]
+    _note("reduce_scatter", 0, 0, send)
     if _has_reduce_scatter():
         out = torch.empty((2, B, D), dtype=send.dtype, device=send.device)
         dist.reduce_scatter_tensor(out.view(2 * B, D), send.view(W * 2 * B, D), op=dist.ReduceOp.SUM)
@@ -122,12 +140,13 @@ class GradReducer:
             self._staging[(key, dtype)] = b
         return b[:n]
 
-    def _mean(self, t):
-        """in-place mean over ranks of the 1-D tensor t (fp32 or bf16)"""
+    def _mean(self, t, begin=0, end=0):
+        """in-place mean over ranks of the 1-D tensor t (fp32 or bf16), the arena range [begin, end)"""
         W = self.W
         self.bytes_sent += t.numel() * t.element_size()
         self.calls += 1
-        if self.algo == "rs_ag" and _has_reduce_scatter():
+        _note("grad_mean:" + self.algo, begin, end, t)
+        if self.algo == "rs_ag":
             n = t.numel()
             per = (n + W - 1) // W
             if per * W != n:                       # pad the tail so that every rank owns an equal shard
@@ -137,8 +156,18 @@ class GradReducer:
             else:
                 padded = t
             shard = self._buf("shard", per, t.dtype)
-            dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.AVG)
-            dist.all_gather_into_tensor(padded, shard)
+            if _has_reduce_scatter():
+                dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.AVG)
+                dist.all_gather_into_tensor(padded, shard)
+            else:
+                # gloo (CPU tests) has neither reduce_scatter nor AVG: the same shard bookkeeping over an all-reduce of the
+                # padded buffer, the owned shard divided, then gathered back -- the ragged-range logic is what is under test
+                dist.all_reduce(padded, op=dist.ReduceOp.SUM)
+                shard.copy_(padded[self.rank * per:(self.rank + 1) * per])
+                shard.div_(W)
+                parts = [torch.empty_like(shard) for _ in range(W)]
+                dist.all_gather(parts, shard)
+                padded.copy_(torch.cat(parts))
             if padded is not t:
                 t.copy_(padded[:n])
         elif _has_reduce_scatter():
@@ -166,10 +195,10 @@ class GradReducer:
                     # arena offsets are multiples of 64 elements, so both views keep the 16-byte alignment of the casts
                     lp = self._buf("lp", piece.numel(), torch.bfloat16)
                     _narrow(piece, lp)
-                    self._mean(lp)
+                    self._mean(lp, a, a + piece.numel())
                     _widen(lp, piece)
                 else:
-                    self._mean(piece)
+                    self._mean(piece, a, a + piece.numel())
         self.pending = True
 
     def wait(self):

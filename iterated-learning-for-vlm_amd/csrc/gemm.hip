@@ -616,20 +616,24 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
     }
 }
 
-template <int TI, int TJ, int RT = 2>
+// bias_in: this lane's four bias values already in registers (the persistent kernel loads them ahead of the tile's main loop:
+// a load issued HERE would have to be waited for with everything older in the queue, i.e. with the next tile's operand prefetch)
+// POOL = false: the caller never has a pool epilogue (the streaming kernels); its code is left out
+template <int TI, int TJ, int RT = 2, bool POOL = true>
 __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
-                                              float alpha, unsigned char* wlds) {
+                                              float alpha, unsigned char* wlds, const f32x4* bias_in = nullptr) {
     const ilvlm_gemm_epilogue& e = ep.e;
     static_assert(TJ == 4 && (TI % RT) == 0, "64-column wave tiles, RT row tiles per pass");
     const bool whole = ep.vec_ok && !e.accumulate && m_base + TI * 16 <= ep.M && n_base + TJ * 16 <= ep.N;
     int mode = EPI_GENERIC;
-    if (e.pool_out) mode = EPI_POOLMAX;
+    if (POOL && e.pool_out) mode = EPI_POOLMAX;
     else if (whole && !e.rowbias) {
         if (e.act == ILVLM_ACT_NONE) mode = e.residual ? EPI_RES : EPI_PLAIN;
         else if (!e.residual) mode = EPI_QGELU + (e.act - ILVLM_ACT_QUICKGELU);
     }
     const int n = n_base + 4 * (lane & 15);          // this lane's columns after the transpose
-    const f32x4 bias = (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0};
+    const f32x4 bias = bias_in ? *bias_in
+                               : ((mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0});
     float amax8 = 0.f;
     switch (mode) {
         case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
@@ -638,7 +642,9 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
         case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
         case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
         case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_POOLMAX: epilogue_pass<EPI_POOLMAX, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        case EPI_POOLMAX:
+            if constexpr (POOL) epilogue_pass<EPI_POOLMAX, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
+            break;
         default: epilogue_pass<EPI_GENERIC, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
     }
     if (e.out8_amax) {          // one conditional atomic per wave and tile
@@ -1192,6 +1198,17 @@ __device__ __forceinline__ void pk_load_b1(bf16x8& b, pk_i32x4 rs, int voff, int
         : "scc");
 }
 
+// four fp32 (one lane's bias values) by an asm load the compiler does not count; `ok` == 0 leaves b as it is
+__device__ __forceinline__ void pk_load_bias(f32x4& b, pk_i32x4 rs, int voff, int soff, int ok) {
+    asm volatile(
+        "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lpk_bias_skip%=\n\t"
+        "buffer_load_dwordx4 %[b], %[vo], %[rs], %[so] offen\n\t"
+        ".Lpk_bias_skip%=:"
+        : [b] "+v"(b)
+        : [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff), [ok] "s"(ok)
+        : "scc");
+}
+
 // interleaved step body: the 16 (NP = 8) / 12 (NP = 4) loads of the NEXT K-tile are issued one by one behind the groups of
 // four MFMAs of the current one, so that a wave's own matrix pipe has work queued while a load instruction issues (a 1 KiB
 // load holds the wave's instruction stream for ~50-100 cycles; issued as one block in front of the MFMAs they cost a wave
@@ -1443,6 +1460,244 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
 #endif
 }
 
+// =====================================================================================
+// Persistent form of the streaming kernel (round 4).  What the one-tile-per-workgroup form above loses on the K = 512...768
+// products of the step is not its main loop (0.42 of the MFMA peak at 4096^3, 0.38-0.44 on ViT-L/14) but everything around it:
+// a workgroup's first operands arrive ~2 us after its launch with nothing to multiply meanwhile, its stores keep the slot
+// until they are acknowledged, and the dispatcher refills the slot only then -- a third of a slot's time at 8-12 K-tiles per
+// tile (in-kernel stamps).  Here a workgroup walks SEVERAL tiles (grid = 2 per CU, tile i of block b is
+// linear position b + i * gridDim.x of the same XCD-aware, L2-blocked tile walk), and the operand stream does not stop at a
+// tile boundary: the K-tiles of a workgroup's tiles form ONE sequence v = 0, 1, 2, ... through the three-stage A ring and
+// the two B register sets, so the last two steps of a tile issue the first loads of the next one (B(0)', A(0)', A(1)') in
+// the load slots that the one-tile form leaves empty, and the epilogue -- LDS transpose, bias / activation / residual,
+// stores -- runs while those loads are in flight.
+//   vmcnt bookkeeping across the epilogue.  Stores count in vmcnt too, so a counted wait behind the epilogue would either
+//   wait for the stores' acknowledgements or depend on loads and stores retiring in ONE order.  Neither: the operands of the
+//   next tile's first step (A(v+1), B(v+1)) are waited for IN FRONT of the epilogue -- `vmcnt(NP)`, which leaves only the
+//   pieces of A(v+2) in flight; they were issued one to two steps earlier, so this wait is short -- and the first step of
+//   the next tile skips its wait.  Its second step waits `vmcnt(NP)` as every step does: whatever the retirement order
+//   between loads and stores, at most NP outstanding operations means that every load older than the NP youngest ones
+//   (the pieces of A(v+3)) has landed, because loads retire in order among themselves.
+//   LDS: EPI_SEP = 1: the epilogue transposes through 8 KiB per wave of its own BEHIND the ring (80 KiB per workgroup, two
+//   workgroups fill the CU's 160 KiB); no barrier is needed around it and waves drift into the next tile on their own.
+//   EPI_SEP = 2: 64 KiB -- two waves through the free stage, two through 16 KiB behind the ring (32-row passes, one barrier).
+//   EPI_SEP = 0: through the stage that the tile's last step has just read (4 KiB per wave at four waves: 16-row passes),
+//   48 KiB per workgroup, one barrier in front of the epilogue; the next step's top barrier orders the transposes
+//   against the DMA that refills the stage.
+// Even K-tile counts only (the B register sets swap roles every step; an odd count would need the loop body twice); every
+// shape of the towers has one.  Same MFMA sequence per output element: bit-identical to the one-tile form.
+// =====================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+// linear position p of the tile walk -> tile coordinates (as in gemm_bf16_pk_kernel: XCD remap, then row bands x column groups)
+template <class EP>
+__device__ __forceinline__ void pk_tile_of(int p, int tiles_m, int tiles_n, const EP& ep, int& tm, int& tn) {
+    const int wg = xcd_remap(p, tiles_m * tiles_n);
+    tn = wg % tiles_n;
+    tm = wg / tiles_n;
+    if (ep.tile_group > 0) {
+        const int idx = wg, Hb = (tiles_m + ep.tile_bands - 1) / ep.tile_bands, G = ep.tile_group;
+        const int band = idx / (Hb * tiles_n), hb = min(Hb, tiles_m - band * Hb);
+        const int r = idx - band * Hb * tiles_n, full = tiles_n / G;
+        int g, gw, rr;
+        if (r < full * hb * G) { g = r / (hb * G); gw = G; rr = r - g * hb * G; }
+        else { g = full; gw = tiles_n - full * G; rr = r - full * hb * G; }
+        tm = band * Hb + rr / gw;
+        tn = g * G + rr % gw;
+    }
+}
+#endif
+
+// One by-value struct = the kernarg segment's layout: the epilogue's arguments (some 50 dwords) are RE-READ from the kernarg
+// segment per tile (scalar loads through a pointer the compiler cannot see through) instead of living in SGPRs across the
+// main loop -- held there they took the kernel to 140 spilled SGPRs (v_writelane / v_readlane in the loop, three more VGPRs,
+// and with those VGPR spills).
+struct PkpArgs {
+    const bf16* A;
+    const bf16* Bp;
+    int lda, K, tiles_m, tiles_n;
+    int stagger;         // shader cycles by which the second half of the grid starts its first tile late (see the kernel)
+    int pad_;
+    EpiArgs ep;
+};
+
+template <int WN, int EPI_SEP>
+__global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);
+    constexpr int STAGE = 128 * 64 * 2;
+    constexpr int EPI_RT = (EPI_SEP || WN == 2) ? 2 : 1;            // row tiles per epilogue pass: 8 KiB or 4 KiB per wave
+    static_assert(EPI_SEP != 2 || WN == 4, "the 64 KiB form splits four waves over the free stage and 16 KiB behind the ring");
+    typedef __attribute__((address_space(4))) const PkpArgs* KernargPtr;
+    const KernargPtr kargs = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const bf16* const A = args.A;
+    const bf16* const Bp = args.Bp;
+    const int lda = args.lda, K = args.K, tiles_m = args.tiles_m, tiles_n = args.tiles_n;
+    struct { int M, N, tile_group, tile_bands; } ep = {args.ep.M, args.ep.N, args.ep.tile_group, args.ep.tile_bands};
+    __builtin_amdgcn_s_setprio(ILVLM_PK_PRIO);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = tiles_m * tiles_n, stride = gridDim.x;
+    const int nt = K >> 6;                                           // even, >= 2 (host check)
+
+    const pk_i32x4 rsa = pk_rsrc(A, ((long)(ep.M - 1) * lda + K) * 2);
+    const int arow = wave * NP * 8 + (lane >> 3);
+    const int a_voff = (arow * lda + (((lane & 7) ^ (arow & 7)) << 3)) * 2;
+    const int a_jstep = 8 * lda * 2;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_raw + wave * NP * 1024;
+    const pk_i32x4 rsb = pk_rsrc(Bp, (long)ep.N * K * 2);
+    const int b_voff = lane * 16;
+    const int kb = (K >> 5) << 10;                                   // bytes per column tile of the packed B
+
+    // (tile coordinates come out of integer divisions, which run on the vector ALU: without the readfirstlane every one of
+    // these wave-uniform values would occupy a VGPR across the main loop)
+    int p = blockIdx.x, tm, tn;
+    pk_tile_of(p, tiles_m, tiles_n, ep, tm, tn);
+    int m0 = __builtin_amdgcn_readfirstlane(tm * 128), n0 = __builtin_amdgcn_readfirstlane(tn * (64 * WN));
+    int a_cur = __builtin_amdgcn_readfirstlane(m0 * lda * 2);                        // byte offset of K-tile 0 of the tile's A rows
+    int b_cur = __builtin_amdgcn_readfirstlane(((n0 >> 4) + wave * 4) * kb);         // ... of the wave's first B column tile
+
+    f32x4 acc[8][4];
+    bf16x8 b0[4][2], b1[4][2];
+    float alpha = args.ep.e.alpha;
+    if (args.ep.e.alpha_ptr) alpha *= *args.ep.e.alpha_ptr;
+    if (args.ep.e.alpha_ptr2) alpha *= *args.ep.e.alpha_ptr2;
+    // consumed HERE: hipcc waits for a load in front of its first use and does not see the asm loads -- first used in the
+    // epilogue, these two scalars would put an `s_waitcnt vmcnt(0)` there, which drains the next tile's prefetch
+    asm volatile("" : "+v"(alpha));
+    alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, alpha)));      // wave-uniform: an SGPR
+    // the bias of a tile (this lane's four columns after the epilogue's transpose) is loaded by an asm statement at the TOP
+    // of the tile, for the same reason; it is older than every load of the tile's main loop, whose counted waits retire it
+    const int has_bias = __builtin_amdgcn_readfirstlane(args.ep.e.bias ? 1 : 0);
+    const pk_i32x4 rsbias = pk_rsrc(args.ep.e.bias, (long)ep.N * 4);
+    f32x4 bias_v = {0, 0, 0, 0};
+
+#ifdef ILVLM_GEMM_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_pre = 0, c_comp = 0, c_epi = 0;
+    STAMP(t_start);
+#define PKP_KEEP() asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][3]))
+#else
+#define PKP_KEEP()
+#endif
+    // prologue in wait order: A(0), B(0), A(1)
+    pk_dma<NP>(rsa, a_voff, a_cur, a_jstep, lds0, 1);
+    pk_load_b(b0, rsb, b_voff, b_cur, b_cur + kb, b_cur + 2 * kb, b_cur + 3 * kb, 1);
+    pk_dma<NP>(rsa, a_voff, a_cur + 128, a_jstep, lds0 + STAGE, 1);
+    // Stagger.  The two workgroups of a CU start together and do equal work, so they run in lock-step: both multiply at the
+    // same time -- the two waves of a SIMD share its matrix pipe, a K-tile takes each ~2000 cycles for 1024 of MFMA -- and then
+    // both store at the same time, every CU of the chip with them: an HBM write burst with the matrix pipes idle (in-kernel
+    // stamps of the up-projection forward: 24 k cycles of multiply phase and 26 k of epilogue per tile for 12 k of MFMA).
+    // The second half of the grid -- by dispatch order the second workgroup of each CU; a speed assumption only -- therefore
+    // starts its first tile late by about one main loop: from then on one workgroup of a CU multiplies while the other
+    // stores, and chip-wide the stores are spread over the whole launch.  Its prologue loads are in flight meanwhile.
+    if (args.stagger > 0 && (int)blockIdx.x * 2 >= (int)gridDim.x) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)args.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+    int st_cur = 0;                 // ring stage of the K-tile being multiplied; runs on across tiles
+    int later = 0;                  // 1 from the second tile on: its first step's operands were waited for in front of the epilogue
+    int has_next;
+    // step T of the current tile: multiply K-tile T; issue B of the next K-tile of the SEQUENCE and A of the one after it --
+    // of this tile while it has them, of the next tile otherwise
+#define PKP_STEP(BCUR, BNXT, T)                                                                                      \
+    do {                                                                                                             \
+        const int tB = (T) + 1, tA = (T) + 2;                                                                        \
+        const int okB = __builtin_amdgcn_readfirstlane((tB < nt || has_next) ? 1 : 0);                               \
+        const int okA = __builtin_amdgcn_readfirstlane((tA < nt || has_next) ? 1 : 0);                               \
+        const int sB = __builtin_amdgcn_readfirstlane(tB < nt ? b_cur + tB * 2048 : b_nxt);                          \
+        const int sA = __builtin_amdgcn_readfirstlane(tA < nt ? a_cur + tA * 128 : a_nxt + (tA - nt) * 128);         \
+        /* 2: no wait (first step of a later tile); 1: leave the NP pieces of the next A in flight; 0: the last step of all */ \
+        const int wcode = __builtin_amdgcn_readfirstlane(((T) == 0 && later) ? 2 : okB);                             \
+        STAMP(p0);                                                                                                   \
+        asm volatile("s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 .Lpkp_w2%=\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpkp_w0%=\n\t"   \
+                     "s_waitcnt vmcnt(%1)\n\ts_branch .Lpkp_w2%=\n\t.Lpkp_w0%=:\n\ts_waitcnt vmcnt(0)\n\t.Lpkp_w2%=:"          \
+                     ::"s"(wcode), "n"(NP) : "memory", "scc");                                                       \
+        pk_landed(BCUR);                                                                                             \
+        STAMP(p1);                                                                                                   \
+        ILVLM_WG_BARRIER();                                                                                          \
+        STAMP(p2);                                                                                                   \
+        const int st_nn = st_cur == 0 ? 2 : st_cur - 1;       /* (st_cur + 2) % 3 */                                 \
+        pk_compute_il<NP>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, sA, a_jstep,                \
+                          lds0 + st_nn * STAGE, rsb, b_voff, sB, sB + kb, sB + 2 * kb, sB + 3 * kb, okB, okA);       \
+        PKP_KEEP();                                                                                                  \
+        st_cur = st_cur == 2 ? 0 : st_cur + 1;                                                                       \
+        STAMP(p4);                                                                                                   \
+        STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_comp, p2, p4);                              \
+    } while (0)
+    do {
+        const int pn = p + stride;
+        has_next = __builtin_amdgcn_readfirstlane(pn < total ? 1 : 0);
+        int tmn, tnn;
+        pk_tile_of(has_next ? pn : p, tiles_m, tiles_n, ep, tmn, tnn);
+        const int m0n = __builtin_amdgcn_readfirstlane(tmn * 128), n0n = __builtin_amdgcn_readfirstlane(tnn * (64 * WN));
+        const int a_nxt = __builtin_amdgcn_readfirstlane(m0n * lda * 2);
+        const int b_nxt = __builtin_amdgcn_readfirstlane(((n0n >> 4) + wave * 4) * kb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+        {
+            int lane_b = lane;                       // (opaque: the offset is recomputed per tile instead of living in a VGPR)
+            asm volatile("" : "+v"(lane_b));
+            pk_load_bias(bias_v, rsbias, (wave * 64 + 4 * (lane_b & 15)) * 4, __builtin_amdgcn_readfirstlane(n0 * 4),
+                         __builtin_amdgcn_readfirstlane(has_bias));
+        }
+        const int pairs = nt >> 1;
+        for (int tp = 0; tp < pairs; ++tp) {
+            PKP_STEP(b0, b1, 2 * tp);
+            PKP_STEP(b1, b0, 2 * tp + 1);
+        }
+        STAMP(e0);
+        // the next tile's first operands, in front of the epilogue's stores (see the header): A(v+1), B(v+1) landed, the
+        // pieces of A(v+2) stay in flight.  On the last tile the last step has drained everything.
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpkp_e%=\n\ts_waitcnt vmcnt(%1)\n\t.Lpkp_e%=:" ::"s"(__builtin_amdgcn_readfirstlane(has_next)), "n"(NP) : "memory", "scc");
+        pk_landed(b0);
+        asm volatile("" : "+v"(bias_v));             // retired by the waits of the main loop (nt >= 2)
+        unsigned char* wlds;
+        if constexpr (EPI_SEP == 1) {
+            wlds = smem_raw + 3 * STAGE + wave * 8192;
+        } else if constexpr (EPI_SEP == 2) {
+            // 64 KiB per workgroup: waves 0, 1 transpose through the stage the last step has read, waves 2, 3 through 16 KiB
+            // behind the ring -- 8 KiB each, the 32-row passes of the one-tile kernel
+            ILVLM_WG_BARRIER();
+            const int st_free = st_cur == 0 ? 2 : st_cur - 1;
+            wlds = wave < 2 ? smem_raw + st_free * STAGE + wave * 8192 : smem_raw + 3 * STAGE + (wave - 2) * 8192;
+        } else {
+            // the stage the last step has read: every wave is done with it behind this barrier
+            ILVLM_WG_BARRIER();
+            const int st_free = st_cur == 0 ? 2 : st_cur - 1;
+            wlds = smem_raw + st_free * STAGE + wave * (STAGE / WN);
+        }
+        STAMP(e1);
+        {
+            KernargPtr kq = kargs;
+            asm volatile("" : "+s"(kq));             // opaque per tile: the loads below cannot be hoisted out of the tile loop
+            const EpiArgs epl = kq->ep;
+            // likewise the lane index: everything the epilogue derives from it (LDS transpose addresses, column offsets) would
+            // otherwise be hoisted out of the tile loop and held in VGPRs across the main loop (7 spilled VGPRs, reloaded with a
+            // vmcnt(0) at the top of every tile)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            epilogue_tile<8, 4, EPI_RT, false>(epl, acc, m0, n0 + wave * 64, lane_e, alpha, wlds, &bias_v);
+        }
+        STAMP(e2);
+        STAMP_ADD(c_pre, e0, e1); STAMP_ADD(c_epi, e1, e2);
+        p = pn; m0 = m0n; n0 = n0n; a_cur = a_nxt; b_cur = b_nxt;
+        later = 1;
+    } while (has_next);
+#undef PKP_STEP
+#undef PKP_KEEP
+#ifdef ILVLM_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_end_);
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 6;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_pre; o[3] = c_comp; o[4] = t_end_ - t_start - c_epi; o[5] = c_epi;
+    }
+#endif
+#endif
+}
+
 // packed copy of one B operand (ilvlm_gemm_pack_b): one thread per 16-byte chunk
 __global__ __launch_bounds__(256) void pack_b_kernel(const bf16* __restrict__ B, int ldb, int trans, int N, int K, bf16* __restrict__ out) {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1629,6 +1884,45 @@ int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int s
     return ILVLM_OK;
 }
 
+// persistent streaming kernel: `slots` workgroups (default two per CU) walk the tiles; a grid smaller than the tile count
+// must be a multiple of 8 so that a workgroup's tiles stay in its XCD's range of the walk
+std::atomic<int> g_pkp_slots{0};      // 0 = two per CU (ilvlm_gemm_set_persistent_slots: tests force the multi-tile path at small sizes)
+std::atomic<int> g_pkp_epi_sep{-1};   // -1 = ILVLM_PKP_EPI_SEP / built-in default
+std::atomic<int> g_pkp_stagger{-1};   // -1 = ILVLM_PKP_STAGGER / built-in default; cycles per K-tile
+
+template <int WN, int EPI_SEP>
+int launch_pkp(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
+    constexpr int bytes = 3 * 128 * 64 * 2 + (EPI_SEP == 1 ? WN * 8192 : EPI_SEP == 2 ? 16384 : 0);
+    auto kern = gemm_bf16_pkp_kernel<WN, EPI_SEP>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    static int cus = 0;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        int dev = 0;
+        if (attr_err == hipSuccess) attr_err = hipGetDevice(&dev);
+        if (attr_err == hipSuccess) attr_err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "gemm_bf16_pkp: setup: %s", hipGetErrorString(attr_err));
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN), total = tm * tn;
+    static const int slots_env = getenv("ILVLM_PKP_SLOTS") ? atoi(getenv("ILVLM_PKP_SLOTS")) : 0;
+    int slots = g_pkp_slots.load(std::memory_order_relaxed);
+    if (slots <= 0) slots = slots_env > 0 ? slots_env : 2 * cus;
+    int grid = total;
+    if (total > slots) grid = slots >= 8 ? (slots & ~7) : 8;
+    if (grid > total) grid = total;
+    PkpArgs args;
+    args.A = A; args.Bp = Bp; args.lda = lda; args.K = K; args.tiles_m = tm; args.tiles_n = tn; args.ep = ep;
+    args.pad_ = 0;
+    // stagger of the second workgroup of each CU: ILVLM_PKP_STAGGER cycles per K-tile of a tile (only where CUs hold two)
+    static const int stagger_env = getenv("ILVLM_PKP_STAGGER") ? atoi(getenv("ILVLM_PKP_STAGGER")) : 0;
+    const int stag = g_pkp_stagger.load(std::memory_order_relaxed);
+    args.stagger = grid > cus ? (stag >= 0 ? stag : stagger_env) * (K / 64) : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), bytes, s, args);
+    ILVLM_LAUNCH_CHECK("gemm_bf16_pkp");
+    return ILVLM_OK;
+}
+
 template <bool TA, bool TB>
 int launch_f32(const float* A, int lda, const float* B, int ldb, int K, int tm, int tn, int split_k, const EpiArgs& ep,
                hipStream_t s) {
@@ -1648,6 +1942,8 @@ inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 //   16           = as 15, but the streaming kernel for EVERY eligible shape with a packed B (tests: short K-loops);
 //   17           = as 16, plus store-type split-K (2..4 slices) wherever the caller offers a slab workspace (tests; opt-in
 //                  for production through ILVLM_PK_SPLITK -- measured slower on the step's shapes);
+//   18           = as 16 with the PERSISTENT streaming kernel (gemm_bf16_pkp_kernel) wherever the K-tile count is even;
+//   19           = as 15 (K >= 512 on the streaming kernels) without the persistent form (the A/B reference of round 4);
 //    5           = always the single-stage direct-to-LDS 128x128 kernel (both operands through LDS; the A/B reference);
 //    0           = the register-staged general kernel only.
 // (Round 3 re-ran round 2's 256x256 phased 8-wave kernel on the inline-asm DMA, i.e. for the first time with loads that stay in
@@ -1773,8 +2069,9 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // (8 K-tiles: its two-deep prologue weighs more); inside the step the K = 512 shapes are 0.3 % better on it too (fewer
         // kernels competing for LDS), hence the threshold of 512.
         static const int pk_min_k = getenv("ILVLM_PK_MIN_K") ? atoi(getenv("ILVLM_PK_MIN_K")) : 512;
-        if ((variant >= 16 || (variant == 15 && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
-            (long)N * K * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
+        // (the kernel addresses A with 32-bit byte offsets through a buffer descriptor: the operand must end below 2 GiB)
+        if (((variant >= 16 && variant != 19) || ((variant == 15 || variant == 19) && K >= pk_min_k)) && epi->b_packed && swap && !trans_a && K % 64 == 0 && N % 16 == 0 && !epi->pool_out &&
+            (long)N * K * 2 < (1L << 31) && ((long)(M - 1) * lda + K) * 2 < (1L << 31) && aligned(epi->b_packed, 16)) {
             static const int pk_wn = getenv("ILVLM_PK_WN") ? atoi(getenv("ILVLM_PK_WN")) : 4;
             const int wn = (pk_wn == 4 && N % 256 == 0) ? 4 : 2;
             const int tn_pk = ceil_div(N, 64 * wn);
@@ -1800,6 +2097,21 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                     sk = want;
                     ep.e.splitk_ws = slab_ws;
                 }
+            }
+            // persistent form: even K-tile counts, no K split
+            static const int pkp_env = getenv("ILVLM_PKP") ? atoi(getenv("ILVLM_PKP")) : 1;
+            static const int pkp_sep_env = getenv("ILVLM_PKP_EPI_SEP") ? atoi(getenv("ILVLM_PKP_EPI_SEP")) : 1;
+            const bool persistent = (variant == 18 || (variant == 15 && pkp_env)) && sk == 1 && (K / 64) % 2 == 0 && K >= 128;
+            if (persistent) {
+                const int sep_sel = g_pkp_epi_sep.load(std::memory_order_relaxed);
+                const int sep = sep_sel < 0 ? pkp_sep_env : sep_sel;
+                const bf16* bp = (const bf16*)epi->b_packed;
+                if (wn == 4) {
+                    if (sep == 1) return launch_pkp<4, 1>(a, lda, bp, K, M, N, ep, s);
+                    if (sep == 2) return launch_pkp<4, 2>(a, lda, bp, K, M, N, ep, s);
+                    return launch_pkp<4, 0>(a, lda, bp, K, M, N, ep, s);
+                }
+                return sep == 1 ? launch_pkp<2, 1>(a, lda, bp, K, M, N, ep, s) : launch_pkp<2, 0>(a, lda, bp, K, M, N, ep, s);
             }
             if (wn == 4) return launch_pk<4>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
             return launch_pk<2>(a, lda, (const bf16*)epi->b_packed, K, M, N, sk, ep, s);
@@ -1854,8 +2166,21 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)
 extern "C" int ilvlm_gemm_set_variant(int variant) {
-    ILVLM_REQUIRE(variant == 0 || variant == 5 || (variant >= 15 && variant <= 17), "gemm_set_variant: 0, 5, 15, 16 or 17");
+    ILVLM_REQUIRE(variant == 0 || variant == 5 || (variant >= 15 && variant <= 19), "gemm_set_variant: 0, 5 or 15..19");
     g_gemm_variant.store(variant, std::memory_order_relaxed);
+    return ILVLM_OK;
+}
+
+// tuning / test hook of the persistent streaming kernel: workgroups per launch (0 = two per CU; tests pass 8 so that small
+// problems walk several tiles per workgroup), where its epilogue transposes (-1 = default, 1 = own LDS behind the operand
+// ring, 0 = through the ring's free stage) and the start delay of the second workgroup of each CU in shader cycles per K-tile
+// of a tile (-1 = default / ILVLM_PKP_STAGGER, 0 = none)
+extern "C" int ilvlm_gemm_set_persistent(int slots, int epi_sep, int stagger) {
+    ILVLM_REQUIRE(slots >= 0 && slots <= 65536 && epi_sep >= -1 && epi_sep <= 2 && stagger >= -1 && stagger <= 100000,
+                  "gemm_set_persistent: slots >= 0, epi_sep in -1..2, stagger in -1..100000");
+    g_pkp_slots.store(slots, std::memory_order_relaxed);
+    g_pkp_epi_sep.store(epi_sep, std::memory_order_relaxed);
+    g_pkp_stagger.store(stagger, std::memory_order_relaxed);
     return ILVLM_OK;
 }
 

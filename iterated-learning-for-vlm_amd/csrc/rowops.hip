@@ -435,14 +435,26 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, float
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
-// out[0] += sum x^2 (one atomic per workgroup); x *= min(1, max_norm / (sqrt(ss[0]) + 1e-6)): clip_grad_norm_ over the flat
-// gradient arena (prototype/utils/grad_clip.py:12-47)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// out[0] += sum x^2; x *= min(1, max_norm / (sqrt(ss[0]) + 1e-6)): clip_grad_norm_ over the flat gradient arena
+// (prototype/utils/grad_clip.py:12-47).  BITWISE REPRODUCIBLE: under data parallelism every rank computes the clip coefficient
+// of the (bit-identical) averaged arena on its own, so a sum whose order depends on workgroup arrival -- one float atomic per
+// workgroup, the first form of this kernel -- lets the replicas drift apart by an ulp per step.  Two launches instead: a fixed
+// grid writes one partial per workgroup (each thread adds its elements in index order, the workgroup reduces in a fixed tree),
+// then ONE workgroup adds the partials in a fixed order and is the only writer of out[0].
+constexpr int SUMSQ_PARTIALS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partials) {
     __shared__ float scratch[8];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
     s = block_sum_256(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int count, float* __restrict__ out) {
+    __shared__ float scratch[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) out[0] += s;
 }
 __global__ __launch_bounds__(256) void clip_by_norm_kernel(float* __restrict__ x, long n, const float* __restrict__ ss, float max_norm) {
     const float coef = max_norm / (sqrtf(ss[0]) + 1e-6f);
@@ -819,9 +831,13 @@ extern "C" int ilvlm_scale_dev(const float* x, float* y, const float* a, long n,
     ILVLM_LAUNCH_CHECK("scale_dev");
     return ILVLM_OK;
 }
-extern "C" int ilvlm_sumsq(const float* x, long n, float* out, void* stream) {
-    ILVLM_REQUIRE(x && out && n > 0, "sumsq: bad args");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_1d(n, 1024, 4096)), dim3(256), 0, S_, x, n, out);
+extern "C" int ilvlm_sumsq_partials(void) { return SUMSQ_PARTIALS; }
+extern "C" int ilvlm_sumsq(const float* x, long n, float* out, float* partials, void* stream) {
+    ILVLM_REQUIRE(x && out && partials && n > 0, "sumsq: bad args (partials: workspace of ilvlm_sumsq_partials() floats)");
+    const int blocks = grid_1d(n, 1024, SUMSQ_PARTIALS);          // depends on n alone: the summation order is a function of n
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, S_, x, n, partials);
+    ILVLM_LAUNCH_CHECK("sumsq");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S_, partials, blocks, out);
     ILVLM_LAUNCH_CHECK("sumsq");
     return ILVLM_OK;
 }

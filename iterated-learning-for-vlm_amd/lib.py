@@ -53,6 +53,7 @@ class AdamWHyper(C.Structure):
 SIGNATURES = {
     "ilvlm_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(GemmEpilogue), i32, vp],
     "ilvlm_gemm_set_variant": [i32],
+    "ilvlm_gemm_set_persistent": [i32, i32, i32],
     "ilvlm_gemm_pack_b": [i32, i32, i32, vp, i32, vp, vp],
     "ilvlm_pack_weights": [vp, vp, vp, vp, i32, vp],
     "ilvlm_wgrad_group": [i32, C.POINTER(WgradProblem), i32, i64, i32, vp],
@@ -96,7 +97,8 @@ SIGNATURES = {
     "ilvlm_scale_dev": [vp, vp, vp, i64, vp],
     "ilvlm_add_inplace": [vp, vp, i64, vp],
     "ilvlm_clamp": [vp, f32, f32, i64, vp],
-    "ilvlm_sumsq": [vp, i64, vp, vp],
+    "ilvlm_sumsq_partials": [],
+    "ilvlm_sumsq": [vp, i64, vp, vp, vp],
     "ilvlm_clip_by_norm": [vp, i64, vp, f32, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],

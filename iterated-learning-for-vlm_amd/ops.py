@@ -333,6 +333,12 @@ def gemm_set_variant(v):
     L.check(L.load().ilvlm_gemm_set_variant(int(v)), "gemm_set_variant")
 
 
+def gemm_set_persistent(slots=0, epi_sep=-1, stagger=-1):
+    """persistent streaming kernel: workgroups per launch (0 = two per CU), epilogue LDS placement (-1 = default) and the start
+    delay of each CU's second workgroup in cycles per K-tile (-1 = default)"""
+    L.check(L.load().ilvlm_gemm_set_persistent(int(slots), int(epi_sep), int(stagger)), "gemm_set_persistent")
+
+
 def rowsum_fusable(m, k):
     """True when a weight-gradient GEMM with output rows m and reduction k can also produce the bias gradient (the
     direct-to-LDS kernel takes any reduction length when both operands are K-strided, as they are in a weight gradient)."""
@@ -762,13 +768,21 @@ def add_inplace(y, x):
     return y
 
 
+_SUMSQ_WS = {}
+
+
 def clip_grad_norm_(flat, max_norm, scratch=None):
     """clip_grad_norm_ (2-norm) over a flat fp32 gradient buffer, entirely on the device; returns the 1-element tensor holding
     the SQUARED total norm (read it only when logging)"""
     _chk(flat, "clip_grad_norm.flat", torch.float32)
     ss = scratch if scratch is not None else torch.empty(1, dtype=torch.float32, device=flat.device)
     ss.zero_()
-    L.check(L.load().ilvlm_sumsq(flat.data_ptr(), flat.numel(), ss.data_ptr(), _stream()), "sumsq")
+    # per-workgroup partials of the (bitwise reproducible) two-stage sum; one small buffer per device, reused on the stream
+    key = flat.device.index
+    part = _SUMSQ_WS.get(key)
+    if part is None:
+        part = _SUMSQ_WS[key] = torch.empty(L.load().ilvlm_sumsq_partials(), dtype=torch.float32, device=flat.device)
+    L.check(L.load().ilvlm_sumsq(flat.data_ptr(), flat.numel(), ss.data_ptr(), part.data_ptr(), _stream()), "sumsq")
     L.check(L.load().ilvlm_clip_by_norm(flat.data_ptr(), flat.numel(), ss.data_ptr(), float(max_norm), _stream()), "clip_by_norm")
     return ss
 

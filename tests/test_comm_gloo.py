@@ -193,11 +193,69 @@ def _worker_trajectory(rank, world, port, ret, bucket):
     dist.destroy_process_group()
 
 
-def _spawn(fn, port, *extra):
+def _spawn(fn, port, *extra, world=2):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(fn, args=(2, port, ret) + tuple(extra), nprocs=2, join=True)
+    mp.spawn(fn, args=(world, port, ret) + tuple(extra), nprocs=world, join=True)
     return dict(ret)
+
+
+def _worker_many(rank, world, port, ret):
+    """what an 8-GPU run relies on and a 2-rank test cannot show: rank-major order and label offsets at W > 2, the sum over
+    MANY ranks in the gathered-gradient exchange, ragged reduce-scatter + all-gather shards (range lengths that W does not
+    divide), bf16 buckets, and one collective SEQUENCE on every rank"""
+    _setup(rank, world, port)
+    torch.set_num_threads(1)
+    from ilvlm_amd import comm
+    from oracle import clip_oracle as O
+    tr = comm.trace(True)
+    ok = True
+    B, D = 3, 8
+    base = torch.arange(B * D, dtype=torch.float32).reshape(B, D)
+    img, txt = base + 1000 * rank, -(base + 1000 * rank) - 0.5
+    g_img, g_txt = comm.gather_pair(img, txt)
+    ok &= g_img.shape == (world * B, D) and g_txt.shape == (world * B, D)
+    for r in range(world):
+        ok &= torch.equal(g_img[r * B:(r + 1) * B], base + 1000 * r)
+        ok &= torch.equal(g_txt[r * B:(r + 1) * B], -(base + 1000 * r) - 0.5)
+    # labels of the non-square logit matrix: rank * B + arange(B) (reference loss.py:42); the diagonal block of this rank's
+    # rows against the gathered columns must be where its own pairs sit
+    li = (img @ g_txt.t())
+    _, labels = O.info_nce(li, li.clone(), rank=rank)
+    ok &= torch.equal(labels, rank * B + torch.arange(B))
+    # gathered-gradient exchange: every rank contributes a full [W*B, D]; rank r keeps rows r*B.. of the SUM over ranks
+    rows = torch.arange(world * B, dtype=torch.float32).reshape(-1, 1)
+    dg_img = (rank + 1) * rows.expand(world * B, D).contiguous()
+    dg_txt = -2.0 * dg_img
+    s_img, s_txt = comm.reduce_gathered(dg_img, dg_txt, B)
+    tot = world * (world + 1) / 2
+    want = tot * rows[rank * B:(rank + 1) * B].expand(B, D)
+    ok &= torch.allclose(s_img, want) and torch.allclose(s_txt, -2.0 * want)
+    # gradient mean over ragged ranges, both algorithms, both bucket dtypes; chunking that cuts ranges unevenly
+    n = 1000 + 37
+    vals = lambda r: (torch.arange(n, dtype=torch.float32) * 0.01 - 3.0) * (r + 1) + r
+    mean = sum(vals(r) for r in range(world)) / world
+    mean_lp = sum(vals(r).bfloat16().float() for r in range(world)) / world
+    for algo in ("allreduce", "rs_ag"):
+        for bucket in ("fp32", "bf16"):
+            flat = vals(rank).clone()
+            red = comm.GradReducer(flat, bucket=bucket, algo=algo)
+            red.reduce_range(64, 64 + 7 * world + 3, chunk_elems=1 << 20)      # a range W does not divide
+            red.reduce_range(256, n, chunk_elems=101)                          # chunks W does not divide, ragged tail
+            red.wait()
+            want = vals(rank).clone()
+            for b, e in ((64, 64 + 7 * world + 3), (256, n)):
+                want[b:e] = (mean_lp if bucket == "bf16" else mean)[b:e]
+            tol = 2.0 ** -6 if bucket == "bf16" else 1e-6
+            good = bool(((flat - want).abs() <= tol * want.abs() + 1e-6).all())
+            untouched = torch.equal(flat[:64], vals(rank)[:64]) and torch.equal(flat[64 + 7 * world + 3:256], vals(rank)[64 + 7 * world + 3:256])
+            ok &= good and untouched
+            if not (good and untouched):
+                print("rank %d: %s / %s wrong: max err %.3e" % (rank, algo, bucket, float((flat - want).abs().max())))
+    ret[rank] = (bool(ok), list(tr))
+    comm.trace(False)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def test_gather_reduce_scatter_and_grad_mean_two_ranks():
@@ -238,3 +296,17 @@ def test_bf16_gradient_buckets_stay_on_the_fp32_bucket_trajectory():
             worst = max(worst, abs(a - b) / abs(b))
     print("bf16 vs fp32 gradient buckets, 2 ranks x 5 steps: largest relative loss difference %.3e" % worst)
     assert worst < 1e-2
+
+
+@pytest.mark.parametrize("world,port", [(4, 29551), (8, 29553)])
+def test_exchange_layer_at_four_and_eight_ranks(world, port):
+    """The 8-GPU node runs what these ranks run (gloo here, RCCL there): rank-major gather order, rank-offset labels, the
+    gathered-gradient sum, gradient means over ranges and chunks that the world size does not divide (reduce-scatter +
+    all-gather shards with a padded tail, bf16 buckets) -- and ONE sequence of collectives on every rank."""
+    ret = _spawn(_worker_many, port, world=world)
+    assert sorted(ret) == list(range(world))
+    for r in range(world):
+        assert ret[r][0], "rank %d" % r
+        assert ret[r][1] == ret[0][1], "rank %d issued a different sequence of collectives than rank 0" % r
+    ops = [t[0] for t in ret[0][1]]
+    assert ops[0] == "all_gather" and ops[1] == "reduce_scatter" and len(ops) == 2 + 4 * (1 + 8)

@@ -464,6 +464,18 @@ def test_clip_grad_norm_over_a_flat_buffer(n, max_norm):
     scratch = torch.full((1,), 123.0, device="cuda")             # a caller-provided accumulator is zeroed first
     ss2 = ops.clip_grad_norm_(raw.clone(), max_norm, scratch)
     assert ss2.data_ptr() == scratch.data_ptr() and abs(float(ss2) - float(tn) ** 2) <= 1e-4 * float(tn) ** 2
+    # bitwise reproducible (data-parallel replicas clip the same averaged arena each on their own and must stay identical):
+    # the same buffer gives the same bits launch after launch, also with other work on the device in between
+    first_ss, first_g = None, None
+    for it in range(6):
+        gi = raw.clone()
+        if it % 2:
+            torch.empty(8 << 20, device="cuda").normal_()
+        si = ops.clip_grad_norm_(gi, max_norm).clone()
+        if first_ss is None:
+            first_ss, first_g = si, gi
+        else:
+            assert torch.equal(si, first_ss) and torch.equal(gi, first_g), "clipped arena differs between launches"
 
 
 def test_adamw_matches_torch():
@@ -631,7 +643,7 @@ def test_weight_gradient_gemm_with_ragged_reduction(K):
     assert rel(bias, a.float().sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [5, 16])
+@pytest.mark.parametrize("variant", [5, 16, 18])
 @pytest.mark.parametrize("M,N,K,tb", [(19712, 2048, 512, 0), (12800, 3072, 768, 0), (12800, 768, 3072, 1), (11319, 1536, 512, 0)])
 def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, tb):
     """Chip-filling launches of the step's shapes, repeated: every launch must reproduce the first bit for bit (no atomics in
@@ -644,7 +656,7 @@ def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, 
     a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
     w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
     ref = a.float() @ (w.float() if tb else w.float().t())
-    wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant == 16 else None
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant >= 16 else None       # 18: the persistent streaming kernel (2 workgroups per CU walk 1.4 .. 4.8 tiles each)
     try:
         ops.gemm_set_variant(5)
         base = torch.empty(M, N, device="cuda", dtype=torch.float32)
@@ -790,6 +802,61 @@ def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, monkeypatch):
     assert rel(got[2], ref + bias + res) < 2e-5
     for i, (g, b) in enumerate(zip(got, base)):
         assert torch.equal(g, b), "epilogue case %d differs from the direct-to-LDS kernel" % i
+
+
+@pytest.mark.parametrize("epi_sep", [1, 0, 2])
+@pytest.mark.parametrize("slots", [8, 24, 0])
+@pytest.mark.parametrize("M,N,K,tb", [(1000, 768, 512, 0), (640, 400, 256, 1), (136, 2304, 768, 0), (776, 528, 128, 1), (2000, 1024, 384, 0),
+                                      (129, 144, 1536, 1), (3000, 512, 2048, 0)])
+def test_persistent_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, slots, epi_sep):
+    """gemm_bf16_pkp_kernel: a workgroup walks several tiles, the operand stream (three-stage A ring, two B register sets) runs on
+    across tile boundaries and the epilogue of a tile runs under the next tile's first loads.  With 8 / 24 workgroups every
+    problem here has 2 .. 48 tiles per workgroup (and workgroups with one tile fewer than others); 0 = two per CU, one tile each.
+    Ragged row tiles, widths that are not multiples of the 256- / 128-column tile, 2 .. 32 K-tiles, both places where the epilogue
+    may transpose; every store epilogue bit for bit against the direct-to-LDS kernel and against an fp32 reference."""
+    ops = _ops()
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
+    wp = ops.gemm_pack_b(w, trans_b=bool(tb))
+    ref = a.float() @ (w.float() if tb else w.float().t())
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    pre = rnd(M, N, seed=6).to(torch.bfloat16).cuda()
+
+    def run(packed):
+        outs = []
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, out, trans_b=bool(tb), b_packed=packed)
+        outs.append(out)
+        outb = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outb, trans_b=bool(tb), b_packed=packed, bias=bias)
+        outs.append(outb)
+        outr = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, outr, trans_b=bool(tb), b_packed=packed, bias=bias, residual=res)
+        outs.append(outr)
+        aux = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        outg = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outg, trans_b=bool(tb), b_packed=packed, bias=bias, aux=aux, act=1)          # QuickGELU forward
+        outs += [outg, aux]
+        outd = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, outd, trans_b=bool(tb), b_packed=packed, aux=pre, act=3)                     # QuickGELU backward
+        outs.append(outd)
+        return outs
+
+    try:
+        ops.gemm_set_persistent(slots, epi_sep, 700 if slots == 24 else 0)      # a start stagger changes timing, never results
+        ops.gemm_set_variant(18)
+        got = run(wp)
+        again = run(wp)
+        ops.gemm_set_variant(5)
+        base = run(None)
+    finally:
+        ops.gemm_set_variant(15)
+        ops.gemm_set_persistent(0, -1, -1)
+    assert rel(got[0], ref) < 2e-5
+    assert rel(got[2], ref + bias + res) < 2e-5
+    for i, (g, b, g2) in enumerate(zip(got, base, again)):
+        assert torch.equal(g, b), "epilogue case %d differs from the direct-to-LDS kernel" % i
+        assert torch.equal(g, g2), "epilogue case %d differs between two launches" % i
 
 
 @pytest.mark.parametrize("M,N,K,split", [(2048, 512, 19712, 6), (3072, 768, 12800, 3), (512, 512, 11319, 16)])
