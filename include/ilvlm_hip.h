@@ -129,8 +129,8 @@ int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, int N, int K,
  * 5 always the single-stage direct-to-LDS 128x128 kernel (the A/B reference); 0 the register-staged general kernel only.  Shapes the direct-to-LDS kernels cannot take (K % 64 != 0, ragged
  * K-strided operands) always use the general kernel. */
 int ilvlm_gemm_set_variant(int variant);
-/* The persistent streaming kernel (default for b_packed products with an even number of 64-deep K-tiles; selector 18 forces
- * it for every eligible shape, 19 = selector 15 without it): `slots` workgroups per launch, each walking several output
+/* The persistent streaming kernel (opt-in: ILVLM_PKP=1, for b_packed products with an even number of 64-deep K-tiles; selector
+ * 18 forces it for every eligible shape, 19 = selector 15 without it): `slots` workgroups per launch, each walking several output
  * tiles with the next tile's operands in flight under the current tile's epilogue (0 = two per CU); epi_sep: where the
  * epilogue transposes, 1 = LDS of its own behind the operand ring (80 KiB per workgroup), 0 = the ring's free stage (48 KiB),
  * 2 = half and half (64 KiB),

@@ -518,14 +518,24 @@ __device__ __forceinline__ long tr8_frag(const unsigned char* tile, int r16, int
 // tile (K-scaling, benchmarks/p8_scaling.py).  The variant is therefore a template parameter picked by one switch, and
 // the row-group loop is a real loop: the executed path of a tile is a few KB.
 enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, EPI_GELU_BWD, EPI_POOLMAX };
+#ifndef ILVLM_EPI_WIDE
+#define ILVLM_EPI_WIDE 1             // 16-byte bf16 stores in the tile epilogue (see epilogue_pass)
+#endif
+
 
 // one pass (32 rows: row tiles 2P, 2P+1) of epilogue_tile; the pass index is a template parameter so that the accumulator
 // array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
 // RT = row tiles per pass: 2 (32 rows, 8 KiB of LDS per wave) or 1 (16 rows, 4 KiB: the persistent kernel, whose operand
 // LDS is being refilled while the epilogue runs)
-template <int MODE, int TI, int TJ, int P, int RT = 2>
+// WIDE (bf16 outputs without an fp8 copy): after the transpose a lane owns EIGHT consecutive columns of a row of an 8-row
+// group (two ds_read_b128), so every global store is 16 bytes per lane -- 8 rows x 128 B per wave instruction, half the store
+// instructions of the 4-column form.  In-kernel stamps put this epilogue at 10 B/cycle/CU whether or not the rest of the chip
+// stores at the same time: it is bound by the number of store instructions (cdna_hip_programming.md T21), not by HBM.
+// `n` is the lane's first column in the mapping in use; bias[1] is used by WIDE only (columns n + 4 .. n + 7).
+template <int MODE, int TI, int TJ, int P, int RT = 2, bool WIDE = false>
 __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n, int lane, float alpha,
-                                              unsigned char* wlds, f32x4 bias, float& amax8) {
+                                              unsigned char* wlds, const f32x4 (&bias2)[2], float& amax8) {
+    const f32x4 bias = bias2[0];
     if constexpr (P < TI / RT) {
         const ilvlm_gemm_epilogue& e = ep.e;
         const int g = lane >> 4, c = lane & 15;
@@ -575,6 +585,47 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
                 const f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
                 epilogue4<bf16>(ep, m_base + P * (16 * RT) + row, n, v, alpha, (e.out8 || e.out8_amax) ? &amax8 : nullptr);
             }
+        } else if constexpr (WIDE) {
+            static_assert(MODE != EPI_RES, "the residual epilogue writes fp32");
+            const int g8 = lane >> 3, c8 = lane & 7;
+#pragma unroll 1
+            for (int h = 0; h < RT; ++h) {           // rows 16h .. 16h+15 of the pass: 2 instructions x 8 rows
+                bf16x8 pre[2];
+                long off[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int m = m_base + P * (16 * RT) + h * 16 + 8 * k + g8;
+                    off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
+                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) pre[k] = *(const bf16x8*)((const bf16*)e.aux + off[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int row = h * 16 + 8 * k + g8;
+                    f32x4 v[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        v[q] = *(const f32x4*)(wlds + row * 256 + (((2 * c8 + q) ^ (row & 15)) << 4));
+                        v[q] = v[q] * alpha + bias2[q];
+                    }
+                    if constexpr (MODE == EPI_QGELU || MODE == EPI_GELU) {
+                        bf16x8 u;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) u[q] = (bf16)v[q >> 2][q & 3];
+                        *(bf16x8*)((bf16*)e.aux + off[k]) = u;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = MODE == EPI_QGELU ? quick_gelu(v[q >> 2][q & 3]) : gelu_erf(v[q >> 2][q & 3]);
+                    }
+                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            v[q >> 2][q & 3] *= MODE == EPI_QGELU_BWD ? quick_gelu_grad((float)pre[k][q]) : gelu_erf_grad((float)pre[k][q]);
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q >> 2][q & 3];
+                    *(bf16x8*)(ep.Cb + off[k]) = o;
+                }
+            }
         } else {
 #pragma unroll 1
             for (int h = 0; h < RT; ++h) {           // rows 16h .. 16h+15 of the pass: 4 instructions x 4 rows
@@ -612,14 +663,19 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();             // the next pass overwrites the image
-        epilogue_pass<MODE, TI, TJ, P + 1, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
+        epilogue_pass<MODE, TI, TJ, P + 1, RT, WIDE>(ep, acc, m_base, n, lane, alpha, wlds, bias2, amax8);
     }
+}
+
+// launch-uniform part of the choice of the 8-column (16-byte bf16 store) epilogue; the per-tile part is "the tile is whole"
+__host__ __device__ __forceinline__ bool epi_wide_cfg(const ilvlm_gemm_epilogue& e) {
+    return e.out_dtype == ILVLM_BF16 && !e.out8 && !e.out8_amax && !e.residual && !e.rowbias && !e.accumulate && !e.pool_out;
 }
 
 // bias_in: this lane's four bias values already in registers (the persistent kernel loads them ahead of the tile's main loop:
 // a load issued HERE would have to be waited for with everything older in the queue, i.e. with the next tile's operand prefetch)
 // POOL = false: the caller never has a pool epilogue (the streaming kernels); its code is left out
-template <int TI, int TJ, int RT = 2, bool POOL = true>
+template <int TI, int TJ, int RT = 2, bool POOL = true, bool ALLOW_WIDE = true>
 __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI][TJ], int m_base, int n_base, int lane,
                                               float alpha, unsigned char* wlds, const f32x4* bias_in = nullptr) {
     const ilvlm_gemm_epilogue& e = ep.e;
@@ -631,22 +687,38 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
         if (e.act == ILVLM_ACT_NONE) mode = e.residual ? EPI_RES : EPI_PLAIN;
         else if (!e.residual) mode = EPI_QGELU + (e.act - ILVLM_ACT_QUICKGELU);
     }
-    const int n = n_base + 4 * (lane & 15);          // this lane's columns after the transpose
-    const f32x4 bias = bias_in ? *bias_in
-                               : ((mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) ? *(const f32x4*)(e.bias + n) : (f32x4){0, 0, 0, 0});
+    // bf16 outputs of whole tiles: 8 columns per lane and 16-byte stores (ILVLM_EPI_WIDE=0 at build time for the A/B)
+    const bool wide = ILVLM_EPI_WIDE && ALLOW_WIDE && epi_wide_cfg(e) && mode != EPI_GENERIC && mode != EPI_POOLMAX && mode != EPI_RES;
+    const int n = wide ? n_base + 8 * (lane & 7) : n_base + 4 * (lane & 15);          // this lane's columns after the transpose
+    f32x4 bias[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+    if (bias_in) {                                   // preloaded by the caller in the mapping epi_wide_cfg() selects
+        bias[0] = bias_in[0];
+        if (wide) bias[1] = bias_in[1];
+    } else if (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) {
+        bias[0] = *(const f32x4*)(e.bias + n);
+        if (wide) bias[1] = *(const f32x4*)(e.bias + n + 4);
+    }
     float amax8 = 0.f;
+#define ILVLM_EPI_CASE(M)                                                                                             \
+    case M:                                                                                                           \
+        if constexpr (ILVLM_EPI_WIDE && ALLOW_WIDE) {                                                                 \
+            if (wide) { epilogue_pass<M, TI, TJ, 0, RT, true>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break; } \
+        }                                                                                                             \
+        epilogue_pass<M, TI, TJ, 0, RT, false>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);                   \
+        break
     switch (mode) {
-        case EPI_PLAIN: epilogue_pass<EPI_PLAIN, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
+        ILVLM_EPI_CASE(EPI_PLAIN);
+        ILVLM_EPI_CASE(EPI_QGELU);
+        ILVLM_EPI_CASE(EPI_GELU);
+        ILVLM_EPI_CASE(EPI_QGELU_BWD);
+        ILVLM_EPI_CASE(EPI_GELU_BWD);
         case EPI_RES: epilogue_pass<EPI_RES, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_QGELU: epilogue_pass<EPI_QGELU, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_GELU: epilogue_pass<EPI_GELU, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_QGELU_BWD: epilogue_pass<EPI_QGELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
-        case EPI_GELU_BWD: epilogue_pass<EPI_GELU_BWD, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
         case EPI_POOLMAX:
             if constexpr (POOL) epilogue_pass<EPI_POOLMAX, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8);
             break;
         default: epilogue_pass<EPI_GENERIC, TI, TJ, 0, RT>(ep, acc, m_base, n, lane, alpha, wlds, bias, amax8); break;
     }
+#undef ILVLM_EPI_CASE
     if (e.out8_amax) {          // one conditional atomic per wave and tile
         amax8 = wave_max(amax8);
         if (lane == 0) fp8_amax_raise(e.out8_amax, amax8);
@@ -693,6 +765,9 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
 }
 #endif
 
+#ifndef ILVLM_PKP_WIDE
+#define ILVLM_PKP_WIDE 0
+#endif
 #ifndef ILVLM_PK_PRIO
 #define ILVLM_PK_PRIO 1               // wave priority of the streaming kernel (see gemm_bf16_pk_kernel)
 #endif
@@ -1570,7 +1645,10 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args)
     // of the tile, for the same reason; it is older than every load of the tile's main loop, whose counted waits retire it
     const int has_bias = __builtin_amdgcn_readfirstlane(args.ep.e.bias ? 1 : 0);
     const pk_i32x4 rsbias = pk_rsrc(args.ep.e.bias, (long)ep.N * 4);
-    f32x4 bias_v = {0, 0, 0, 0};
+    f32x4 bias_v[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+    // (the 8-column epilogue takes this kernel past its register budget -- 12 spilled VGPRs, reloaded behind a vmcnt(0) -- so it
+    // keeps the 4-column form unless built with -DILVLM_PKP_WIDE=1)
+    const int wide_cfg = __builtin_amdgcn_readfirstlane((ILVLM_EPI_WIDE != 0 && ILVLM_PKP_WIDE != 0 && epi_wide_cfg(args.ep.e)) ? 1 : 0);
 
 #ifdef ILVLM_GEMM_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_pre = 0, c_comp = 0, c_epi = 0;
@@ -1639,8 +1717,11 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args)
         {
             int lane_b = lane;                       // (opaque: the offset is recomputed per tile instead of living in a VGPR)
             asm volatile("" : "+v"(lane_b));
-            pk_load_bias(bias_v, rsbias, (wave * 64 + 4 * (lane_b & 15)) * 4, __builtin_amdgcn_readfirstlane(n0 * 4),
-                         __builtin_amdgcn_readfirstlane(has_bias));
+            const int hb = __builtin_amdgcn_readfirstlane(has_bias);
+            const int wc = __builtin_amdgcn_readfirstlane(wide_cfg);
+            const int bvo = wc ? (wave * 64 + 8 * (lane_b & 7)) * 4 : (wave * 64 + 4 * (lane_b & 15)) * 4;
+            pk_load_bias(bias_v[0], rsbias, bvo, __builtin_amdgcn_readfirstlane(n0 * 4), hb);
+            if constexpr (ILVLM_PKP_WIDE != 0) pk_load_bias(bias_v[1], rsbias, bvo, __builtin_amdgcn_readfirstlane(n0 * 4 + 16), hb & wc);
         }
         const int pairs = nt >> 1;
         for (int tp = 0; tp < pairs; ++tp) {
@@ -1652,7 +1733,8 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args)
         // pieces of A(v+2) stay in flight.  On the last tile the last step has drained everything.
         asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lpkp_e%=\n\ts_waitcnt vmcnt(%1)\n\t.Lpkp_e%=:" ::"s"(__builtin_amdgcn_readfirstlane(has_next)), "n"(NP) : "memory", "scc");
         pk_landed(b0);
-        asm volatile("" : "+v"(bias_v));             // retired by the waits of the main loop (nt >= 2)
+        asm volatile("" : "+v"(bias_v[0]));             // retired by the waits of the main loop (nt >= 2)
+        if constexpr (ILVLM_PKP_WIDE != 0) asm volatile("" : "+v"(bias_v[1]));
         unsigned char* wlds;
         if constexpr (EPI_SEP == 1) {
             wlds = smem_raw + 3 * STAGE + wave * 8192;
@@ -1678,7 +1760,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args)
             // vmcnt(0) at the top of every tile)
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
-            epilogue_tile<8, 4, EPI_RT, false>(epl, acc, m0, n0 + wave * 64, lane_e, alpha, wlds, &bias_v);
+            epilogue_tile<8, 4, EPI_RT, false, ILVLM_PKP_WIDE != 0>(epl, acc, m0, n0 + wave * 64, lane_e, alpha, wlds, bias_v);
         }
         STAMP(e2);
         STAMP_ADD(c_pre, e0, e1); STAMP_ADD(c_epi, e1, e2);
@@ -2099,8 +2181,12 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
                 }
             }
             // persistent form: even K-tile counts, no K split
-            static const int pkp_env = getenv("ILVLM_PKP") ? atoi(getenv("ILVLM_PKP")) : 1;
-            static const int pkp_sep_env = getenv("ILVLM_PKP_EPI_SEP") ? atoi(getenv("ILVLM_PKP_EPI_SEP")) : 1;
+            // Opt-in (ILVLM_PKP=1; selector 18 in the tests): measured round 4, same box -- alone +1..5 % on the launches with more
+            // tiles than workgroup slots, but 16.75 -> 16.9 ms in the step with 64 KiB of LDS and 17.2 ms with 80 KiB (fewer
+            // co-resident weight-gradient workgroups), and no start stagger helps (profiles/round4/).  The in-kernel stamps say why
+            // the one-tile form loses little: a tile's first operands cost ~2 k of its ~55 k cycles.
+            static const int pkp_env = getenv("ILVLM_PKP") ? atoi(getenv("ILVLM_PKP")) : 0;
+            static const int pkp_sep_env = getenv("ILVLM_PKP_EPI_SEP") ? atoi(getenv("ILVLM_PKP_EPI_SEP")) : 2;
             const bool persistent = (variant == 18 || (variant == 15 && pkp_env)) && sk == 1 && (K / 64) % 2 == 0 && K >= 128;
             if (persistent) {
                 const int sep_sel = g_pkp_epi_sep.load(std::memory_order_relaxed);

@@ -198,11 +198,15 @@ def test_solver_with_string_captions_through_the_prefetcher(tmp_path, golden_dir
     assert len(losses) == 3 and np.allclose(losses, losses2, rtol=2e-5, atol=1e-6), (losses, losses2)
 
 
-def test_full_size_step_properties():
-    """BASELINE configs[1] shapes (ViT-B/32 + FDT, per-GPU batch 256, bf16): size-independent properties of the step --
-    the two logit matrices are transposes of each other on one GPU, the loss starts near ln(B), packed text rows and all
-    positions agree, every gradient is finite, the parameters the FDT loss never reaches get none, and a few AdamW steps
-    on a fixed batch lower the loss."""
+@pytest.mark.parametrize("model_name,precision,batch", [("vitb32", "bf16", 256), ("vitb32", "fp8", 512), ("vitl14", "bf16", 128)],
+                         ids=["configs1_vitb32_bf16_b256", "configs4_vitb32_fp8_b512", "configs3_vitl14_bf16_b128"])
+def test_full_size_step_properties(model_name, precision, batch):
+    """The single-GPU forms of BASELINE configs[1] (ViT-B/32 + FDT, bf16, per-GPU batch 256), configs[4] (the fp8 path at ITS
+    per-GPU batch, 4096 / 8 = 512) and configs[3] (ViT-L/14 + FDT, bf16, 1024 / 8 = 128) at full size: size-independent
+    properties of the step -- the two logit matrices are transposes of each other on one GPU, the loss starts near ln(B),
+    packed text rows and all positions agree, every gradient is finite, the parameters the FDT loss never reaches get none,
+    and a few AdamW steps on a fixed batch lower the loss.  (fp8: the first training forward only observes amax values, so the
+    comparison of the two text layouts runs on its second and third forward, with delayed scales in use.)"""
     import math
     import bench as B
     from ilvlm_amd import ops
@@ -211,9 +215,15 @@ def test_full_size_step_properties():
     from ilvlm_amd.prototype.optimizer import optim_entry
     from ilvlm_amd.prototype.utils.misc import param_group_all
     torch.manual_seed(0)
-    model = model_entry(dict(type="clip_fdt_vitb32", kwargs=B.fdt_kwargs("bf16"))).cuda().train()
-    images, tokens, pad, lens = B.synthetic_batch(256, 0, "cuda")
+    model = model_entry(dict(type="clip_fdt_vitb32" if model_name == "vitb32" else "clip_fdt_vitL14",
+                             kwargs=B.fdt_kwargs(precision, model_name))).cuda().train()
+    images, tokens, pad, lens = B.synthetic_batch(batch, 0, "cuda")
     crit = ClipInfoCELoss()
+    if precision == "fp8":                       # observing step: fills the amax history
+        (li, lt), _ = model(images, (tokens, pad, lens))
+        loss, _ = crit(li, lt)
+        model.zero_grad()
+        loss.backward()
     outs = {}
     for name, texts in (("packed", (tokens, pad, lens)), ("dense", (tokens, pad))):
         (li, lt), _ = model(images, texts)
@@ -222,8 +232,8 @@ def test_full_size_step_properties():
         loss.backward()
         torch.cuda.synchronize()
         outs[name] = (li.detach().float().cpu(), lt.detach().float().cpu(), loss.item())
-        assert li.shape == (256, 256) and torch.allclose(li, lt.t(), rtol=1e-4, atol=1e-4)
-        assert abs(loss.item() - math.log(256)) < 0.5
+        assert li.shape == (batch, batch) and torch.allclose(li, lt.t(), rtol=1e-4, atol=1e-4)
+        assert abs(loss.item() - math.log(batch)) < 0.5
         unused = set(model.unused_parameter_names())
         for n, p in model.named_parameters():
             if n in unused or not p.requires_grad:
@@ -231,8 +241,10 @@ def test_full_size_step_properties():
             else:
                 assert torch.isfinite(p.grad).all(), n
     scale = float(outs["dense"][0].abs().max())
-    assert float((outs["packed"][0] - outs["dense"][0]).abs().max()) / scale < 1e-2
-    assert abs(outs["packed"][2] - outs["dense"][2]) < 1e-2 * abs(outs["dense"][2])
+    # fp8: the two layouts quantise different row sets with scales from different histories -- equal to fp8 rounding
+    tol = 1e-2 if precision != "fp8" else 6e-2
+    assert float((outs["packed"][0] - outs["dense"][0]).abs().max()) / scale < tol
+    assert abs(outs["packed"][2] - outs["dense"][2]) < tol * abs(outs["dense"][2])
     groups = param_group_all(model, B.PCONFIG)[0]
     opt = optim_entry(dict(type="AdamW", kwargs=dict(params=groups, lr=5e-4, weight_decay=0.1, betas=[0.9, 0.98], eps=1e-8)))
     losses = []
