@@ -352,6 +352,14 @@ typedef struct ilvlm_adamw_hyper {
 int ilvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                      const int64_t* chunk_offset, const int32_t* chunk_count, const int32_t* chunk_group,
                      int n_chunks, const ilvlm_adamw_hyper* hyper, void* stream);
+/* The same update over the GEMM weights that the streaming kernel reads in MFMA-fragment order, tile by tile (64 x 64), writing
+ * -- besides parameters, moments and the row-major bf16 shadow -- the tile's part of both fragment-order images
+ * (ilvlm_pack_weights' fwd / bwd buffers): the optimizer keeps the packed copies current itself and the per-step re-pack launch
+ * disappears.  tile_table: n_tiles x 6 int32 {arena offset / 64, rows, cols, r0, c0, param group}; such weights must NOT also
+ * appear in the chunk table of ilvlm_adamw_step.  A tile whose group is inactive is left untouched (images included). */
+int ilvlm_adamw_step_packed(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                            void* packed_fwd, void* packed_bwd, const int32_t* tile_table, int n_tiles,
+                            const ilvlm_adamw_hyper* hyper, void* stream);
 
 /* ---- composite: one residual attention block per call (image_encoder/base_transformer.py:29-62, text twin
  * text_encoder/base_transformer.py:29-59): x_mid = x + out_proj(attn(in_proj(ln_1 x))), x_out = x_mid +
@@ -407,6 +415,35 @@ int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, 
                     float* din_f32, void* din_lp, void* scratch, float* ln_ws, int ln_ws_blocks, long rows, int B, int L,
                     int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream, const void* dx8,
                     void* din8, const float* din8_scale, float* din8_amax);
+
+/* ---- composite: a whole tower per call.  The caller allocates, for the n_blocks blocks of a tower (all of one width E):
+ *   xs      [n_blocks, rows, E] fp32: xs[i] = output of block i (the input of block i is xs[i - 1], x0 for block 0);
+ *   saved   n_blocks x saved_stride bytes (>= ilvlm_block_saved_bytes of every block);
+ *   d_f32   [n_blocks, rows, E] fp32: d_f32[i] receives the gradient of block i's INPUT; dtop_* is the gradient of the last
+ *           block's output; per_block[i].din_lp / din8: where the compute-dtype / e5m2 copies of d_f32[i] go (NULL: not produced,
+ *           exactly as the din_lp / din8 arguments of ilvlm_block_bwd), with the e5m2 copy's scale and amax slots;
+ *           per_block[i].ln_ws / ln_ws_blocks: as in ilvlm_block_bwd;
+ *   scratch n_blocks x scratch_stride bytes, untouched until the weight-gradient stream has been joined.
+ * The functions walk the blocks (forward 0 .. n-1, backward n-1 .. 0) through ilvlm_block_fwd / ilvlm_block_bwd: the same
+ * kernels in the same order on the same streams, one call per tower instead of one per block (host time).  `done` (nullable)
+ * runs on the calling thread after block i's backward has been enqueued -- the hook of the data-parallel gradient reducer
+ * (reference prototype/utils/torch_ddp_dist.py:52-67 starts a bucket's all-reduce when its gradients are ready). */
+typedef struct ilvlm_tower_grad {
+    void* din_lp;
+    void* din8;
+    const float* din8_scale;
+    float* din8_amax;
+    float* ln_ws;
+    int ln_ws_blocks;
+    int pad_;
+} ilvlm_tower_grad;
+typedef void (*ilvlm_block_done_fn)(int block, void* user);
+int ilvlm_tower_fwd(const ilvlm_block* blocks, int n_blocks, const float* x0, float* xs, void* saved, long saved_stride, long rows,
+                    int B, int L, int Lcap, const int32_t* seq_offs, void* stream);
+int ilvlm_tower_bwd(const ilvlm_block* blocks, int n_blocks, const ilvlm_tower_grad* per_block, const float* x0, const float* xs,
+                    const void* saved, long saved_stride, const float* dtop_f32, const void* dtop_lp, float* d_f32, void* scratch,
+                    long scratch_stride, long rows, int B, int L, int Lcap, const int32_t* seq_offs, int wgrad_target, void* stream,
+                    void* wgrad_stream, ilvlm_block_done_fn done, void* user);
 /* fp8 mode (b->fp8 >= 2), all four nullable.  With b->fp8 == 3 and all four weight gradients requested, dx_lp may be NULL
  * when dx8 is given and din_lp may be NULL when din8 is given (every consumer then reads the e5m2 copy): dx8 = e5m2 copy of dx_lp if the producer already made one (the previous call's
  * din8), else the call quantises dx_lp itself; din8 [rows, E] bytes receives the e5m2 copy of din_lp, quantised with

@@ -445,3 +445,55 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
                                   lp ? din_lp : nullptr, T, 0,
                                   nullptr, b->g_ln1_w, b->g_ln1_b, rows, E, 0, 0, ln_ws1, ln_ws_blocks, din8, din8_scale, din8_amax, s);
 }
+
+
+// ---- composite: a whole tower (n_blocks residual attention blocks) per call -----------------------------------------------
+// The block calls above cut ~800 Python-level operations per step to 48; what remains of the host's 7-10 ms per step is the
+// interpreter work AROUND each of those 48 calls (descriptor lookup, two or three allocations, argument marshalling, the
+// bookkeeping of the weight-gradient stream).  Here a tower is ONE call: the caller allocates the activations, gradients and
+// scratch of all blocks as a few big buffers, and these functions walk the blocks, calling the block entry points above with
+// pointers into them -- the same kernels in the same order on the same streams.  `done` (nullable) is called on the host
+// after block i's backward has been enqueued: the data-parallel reducer starts that block's gradient mean from it.
+extern "C" int ilvlm_tower_fwd(const ilvlm_block* blocks, int n_blocks, const float* x0, float* xs, void* saved, long saved_stride,
+                               long rows, int B, int L, int Lcap, const int32_t* seq_offs, void* stream) {
+    ILVLM_REQUIRE(blocks && n_blocks > 0 && x0 && xs && saved && rows > 0, "tower_fwd: bad arguments");
+    const int E = blocks[0].E;
+    for (int i = 0; i < n_blocks; ++i) {
+        ILVLM_REQUIRE(blocks[i].E == E, "tower_fwd: block %d has width %d, block 0 has %d", i, blocks[i].E, E);
+        const long need = ilvlm_block_saved_bytes(&blocks[i], rows, B, L);
+        ILVLM_REQUIRE(need > 0 && need <= saved_stride, "tower_fwd: block %d needs %ld bytes of saved activations, stride is %ld", i, need,
+                      saved_stride);
+        const float* x_in = i ? xs + (size_t)(i - 1) * rows * E : x0;
+        TRY(ilvlm_block_fwd(&blocks[i], x_in, xs + (size_t)i * rows * E, (char*)saved + (size_t)i * saved_stride, rows, B, L, Lcap, seq_offs,
+                            stream));
+    }
+    return ILVLM_OK;
+}
+
+extern "C" int ilvlm_tower_bwd(const ilvlm_block* blocks, int n_blocks, const ilvlm_tower_grad* per_block, const float* x0,
+                               const float* xs, const void* saved, long saved_stride, const float* dtop_f32, const void* dtop_lp,
+                               float* d_f32, void* scratch, long scratch_stride, long rows, int B, int L, int Lcap,
+                               const int32_t* seq_offs, int wgrad_target, void* stream, void* wgrad_stream,
+                               ilvlm_block_done_fn done, void* user) {
+    ILVLM_REQUIRE(blocks && per_block && n_blocks > 0 && x0 && xs && saved && dtop_f32 && d_f32 && scratch && rows > 0,
+                  "tower_bwd: bad arguments");
+    const int E = blocks[0].E;
+    for (int i = n_blocks - 1; i >= 0; --i) {
+        ILVLM_REQUIRE(blocks[i].E == E, "tower_bwd: block %d has width %d, block 0 has %d", i, blocks[i].E, E);
+        ILVLM_REQUIRE(ilvlm_block_saved_bytes(&blocks[i], rows, B, L) <= saved_stride &&
+                          ilvlm_block_scratch_bytes(&blocks[i], rows) <= scratch_stride,
+                      "tower_bwd: block %d does not fit the saved / scratch strides", i);
+        const bool top = i == n_blocks - 1;
+        const ilvlm_tower_grad& g = per_block[i];
+        const float* x_in = i ? xs + (size_t)(i - 1) * rows * E : x0;
+        // gradient of block i's output: the caller's for the last block, else what block i + 1 wrote for its input
+        const float* dx_f32 = top ? dtop_f32 : d_f32 + (size_t)(i + 1) * rows * E;
+        const void* dx_lp = top ? dtop_lp : per_block[i + 1].din_lp;
+        const void* dx8 = top ? nullptr : per_block[i + 1].din8;
+        TRY(ilvlm_block_bwd(&blocks[i], x_in, (const char*)saved + (size_t)i * saved_stride, dx_f32, dx_lp, d_f32 + (size_t)i * rows * E,
+                            g.din_lp, (char*)scratch + (size_t)i * scratch_stride, g.ln_ws, g.ln_ws_blocks, rows, B, L, Lcap, seq_offs,
+                            wgrad_target, stream, wgrad_stream, dx8, g.din8, g.din8_scale, g.din8_amax));
+        if (done) done(i, user);
+    }
+    return ILVLM_OK;
+}

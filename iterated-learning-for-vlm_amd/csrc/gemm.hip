@@ -22,6 +22,7 @@ struct EpiArgs {
     int ldc;
     int M, N;
     int vec_ok;    // N%4==0 && ldc%4==0 and all pointers 16B aligned
+    int vec8_ok;   // additionally ldc%8==0 and C / aux 16-byte, the fp8 copy 8-byte aligned: the 8-column (16-byte bf16 store) epilogue
     int tile_group;   // store-type launches walk tiles in column groups of this width inside row bands (L2 blocking); 0 = off
     int tile_bands;   // number of row bands (8 = about one per XCD)
     int plain_acc;    // accumulate launches: this launch is the only writer of C and split_k == 1 -> load-add-store, no atomics
@@ -527,7 +528,9 @@ enum { EPI_GENERIC = 0, EPI_PLAIN, EPI_RES, EPI_QGELU, EPI_GELU, EPI_QGELU_BWD, 
 // array is only ever indexed with constants (a run-time pass loop sends all of it through scratch memory)
 // RT = row tiles per pass: 2 (32 rows, 8 KiB of LDS per wave) or 1 (16 rows, 4 KiB: the persistent kernel, whose operand
 // LDS is being refilled while the epilogue runs)
-// WIDE (bf16 outputs without an fp8 copy): after the transpose a lane owns EIGHT consecutive columns of a row of an 8-row
+__device__ __forceinline__ void out8_store8(const ilvlm_gemm_epilogue& e, long off, f32x4 v0, f32x4 v1, float& amax);
+
+// WIDE (bf16 outputs, with or without an fp8 copy): after the transpose a lane owns EIGHT consecutive columns of a row of an 8-row
 // group (two ds_read_b128), so every global store is 16 bytes per lane -- 8 rows x 128 B per wave instruction, half the store
 // instructions of the 4-column form.  In-kernel stamps put this epilogue at 10 B/cycle/CU whether or not the rest of the chip
 // stores at the same time: it is bound by the number of store instructions (cdna_hip_programming.md T21), not by HBM.
@@ -588,42 +591,54 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
         } else if constexpr (WIDE) {
             static_assert(MODE != EPI_RES, "the residual epilogue writes fp32");
             const int g8 = lane >> 3, c8 = lane & 7;
+            constexpr bool BWD = MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD;
+            constexpr bool FWD_ACT = MODE == EPI_QGELU || MODE == EPI_GELU;
+            // the 64 x 64 wave tiles belong to kernels capped at 128 VGPRs (four workgroups per CU): the second half of the bias
+            // is fetched per pass (an L1 hit) instead of living in four more registers across the passes -- held there it was
+            // spilled to scratch and reloaded per pass anyway
+            f32x4 bias_hi = bias2[1];
+            if constexpr (TI <= 4) bias_hi = e.bias ? *(const f32x4*)(e.bias + n + 4) : (f32x4){0, 0, 0, 0};
 #pragma unroll 1
             for (int h = 0; h < RT; ++h) {           // rows 16h .. 16h+15 of the pass: 2 instructions x 8 rows
                 bf16x8 pre[2];
                 long off[2];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2; ++k) {        // both loads of the half-pass before its first store (vmcnt counts both)
                     const int m = m_base + P * (16 * RT) + h * 16 + 8 * k + g8;
                     off[k] = map_row(m, e.out_group, e.out_skip) * (long)ep.ldc + n;
-                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) pre[k] = *(const bf16x8*)((const bf16*)e.aux + off[k]);
+                    if constexpr (BWD) pre[k] = *(const bf16x8*)((const bf16*)e.aux + off[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int row = h * 16 + 8 * k + g8;
-                    f32x4 v[2];
+                    bf16x8 o, u;
+                    f32x4 vq[2];
+                    // one 4-column half at a time, finished (activation, rounding) before the other is read: the 128-VGPR
+                    // kernels (four workgroups per CU) have no room for eight activation chains in flight
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        v[q] = *(const f32x4*)(wlds + row * 256 + (((2 * c8 + q) ^ (row & 15)) << 4));
-                        v[q] = v[q] * alpha + bias2[q];
+                        f32x4 v = *(const f32x4*)(wlds + row * 256 + (((2 * c8 + q) ^ (row & 15)) << 4));
+                        v = v * alpha + (q == 0 ? bias : bias_hi);
+                        if constexpr (FWD_ACT) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                u[4 * q + j] = (bf16)v[j];
+                                v[j] = MODE == EPI_QGELU ? quick_gelu(v[j]) : gelu_erf(v[j]);
+                            }
+                        }
+                        if constexpr (BWD) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                v[j] *= MODE == EPI_QGELU_BWD ? quick_gelu_grad((float)pre[k][4 * q + j]) : gelu_erf_grad((float)pre[k][4 * q + j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[4 * q + j] = (bf16)v[j];
+                        vq[q] = v;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (MODE == EPI_QGELU || MODE == EPI_GELU) {
-                        bf16x8 u;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) u[q] = (bf16)v[q >> 2][q & 3];
-                        *(bf16x8*)((bf16*)e.aux + off[k]) = u;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = MODE == EPI_QGELU ? quick_gelu(v[q >> 2][q & 3]) : gelu_erf(v[q >> 2][q & 3]);
-                    }
-                    if constexpr (MODE == EPI_QGELU_BWD || MODE == EPI_GELU_BWD) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            v[q >> 2][q & 3] *= MODE == EPI_QGELU_BWD ? quick_gelu_grad((float)pre[k][q]) : gelu_erf_grad((float)pre[k][q]);
-                    }
-                    bf16x8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q >> 2][q & 3];
-                    *(bf16x8*)(ep.Cb + off[k]) = o;
+                    if constexpr (FWD_ACT) *(bf16x8*)((bf16*)e.aux + off[k]) = u;
+                    if (ep.Cb) *(bf16x8*)(ep.Cb + off[k]) = o;                    // (null: only the fp8 copy of the result is kept)
+                    if (e.out8 || e.out8_amax) out8_store8(e, off[k], vq[0], vq[1], amax8);
                 }
             }
         } else {
@@ -669,7 +684,19 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
 
 // launch-uniform part of the choice of the 8-column (16-byte bf16 store) epilogue; the per-tile part is "the tile is whole"
 __host__ __device__ __forceinline__ bool epi_wide_cfg(const ilvlm_gemm_epilogue& e) {
-    return e.out_dtype == ILVLM_BF16 && !e.out8 && !e.out8_amax && !e.residual && !e.rowbias && !e.accumulate && !e.pool_out;
+    return e.out_dtype == ILVLM_BF16 && !e.residual && !e.rowbias && !e.accumulate && !e.pool_out;
+}
+// fp8 copy of 8 stored values (one 8-byte store) + running max|value| for the amax: the 8-column form of out8_store
+__device__ __forceinline__ void out8_store8(const ilvlm_gemm_epilogue& e, long off, f32x4 v0, f32x4 v1, float& amax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
+    if (!e.out8) return;
+    const float s = e.out8_scale ? e.out8_scale[0] : 1.f;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 w;
+    w[0] = fp8_pack4_fmt(e.out8_fmt, v0[0] * s, v0[1] * s, v0[2] * s, v0[3] * s);
+    w[1] = fp8_pack4_fmt(e.out8_fmt, v1[0] * s, v1[1] * s, v1[2] * s, v1[3] * s);
+    *(u32x2*)((unsigned char*)e.out8 + off) = w;
 }
 
 // bias_in: this lane's four bias values already in registers (the persistent kernel loads them ahead of the tile's main loop:
@@ -688,7 +715,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
         else if (!e.residual) mode = EPI_QGELU + (e.act - ILVLM_ACT_QUICKGELU);
     }
     // bf16 outputs of whole tiles: 8 columns per lane and 16-byte stores (ILVLM_EPI_WIDE=0 at build time for the A/B)
-    const bool wide = ILVLM_EPI_WIDE && ALLOW_WIDE && epi_wide_cfg(e) && mode != EPI_GENERIC && mode != EPI_POOLMAX && mode != EPI_RES;
+    const bool wide = ILVLM_EPI_WIDE && ALLOW_WIDE && ep.vec8_ok && epi_wide_cfg(e) && mode != EPI_GENERIC && mode != EPI_POOLMAX && mode != EPI_RES;
     const int n = wide ? n_base + 8 * (lane & 7) : n_base + 4 * (lane & 15);          // this lane's columns after the transpose
     f32x4 bias[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
     if (bias_in) {                                   // preloaded by the caller in the mapping epi_wide_cfg() selects
@@ -696,7 +723,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& ep, f32x4 (&acc)[TI
         if (wide) bias[1] = bias_in[1];
     } else if (mode != EPI_GENERIC && mode != EPI_POOLMAX && e.bias) {
         bias[0] = *(const f32x4*)(e.bias + n);
-        if (wide) bias[1] = *(const f32x4*)(e.bias + n + 4);
+        if (wide && TI > 4) bias[1] = *(const f32x4*)(e.bias + n + 4);
     }
     float amax8 = 0.f;
 #define ILVLM_EPI_CASE(M)                                                                                             \
@@ -1648,7 +1675,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pkp_kernel(PkpArgs args)
     f32x4 bias_v[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
     // (the 8-column epilogue takes this kernel past its register budget -- 12 spilled VGPRs, reloaded behind a vmcnt(0) -- so it
     // keeps the 4-column form unless built with -DILVLM_PKP_WIDE=1)
-    const int wide_cfg = __builtin_amdgcn_readfirstlane((ILVLM_EPI_WIDE != 0 && ILVLM_PKP_WIDE != 0 && epi_wide_cfg(args.ep.e)) ? 1 : 0);
+    const int wide_cfg = __builtin_amdgcn_readfirstlane((ILVLM_EPI_WIDE != 0 && ILVLM_PKP_WIDE != 0 && args.ep.vec8_ok && epi_wide_cfg(args.ep.e)) ? 1 : 0);
 
 #ifdef ILVLM_GEMM_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_pre = 0, c_comp = 0, c_epi = 0;
@@ -2111,6 +2138,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     };
     size_t caln = epi->out_dtype == ILVLM_F32 ? 16 : 8;
     size_t auxaln = compute_dtype == ILVLM_F32 ? 16 : 8;
+    ep.vec8_ok = (ldc % 8 == 0) && aligned(C, 16) && (!epi->aux || aligned(epi->aux, 16)) && (!epi->out8 || aligned(epi->out8, 8)) &&
+                 (!epi->bias || aligned(epi->bias, 16));
     if (fp8) {      // two fp8 elements are addressed as one bf16 element (gemm_bf16_dma_kernel, FP8)
         ep.vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && aligned(C, caln) && (!epi->bias || aligned(epi->bias, 16)) &&
                     (!epi->rowbias || aligned(epi->rowbias, 16)) && (!epi->residual || aligned(epi->residual, 16)) &&
@@ -2304,6 +2333,9 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
                       i, f8 ? 16 : 8);
         ILVLM_REQUIRE(aligned(q.dy, 16) && aligned(q.x, 16) && aligned(q.gw, 4), "wgrad_group: problem %d: operand alignment", i);
         ILVLM_REQUIRE(!f8 || (q.inv_g && q.inv_x), "wgrad_group: problem %d: fp8 operands need their scales", i);
+        // both operands are addressed through 32-bit byte offsets of a buffer descriptor: they must end below 2 GiB
+        ILVLM_REQUIRE(((rows - 1) * (long)q.n + q.n) * (f8 ? 1 : 2) < (1L << 31) && ((rows - 1) * (long)q.k + q.k) * (f8 ? 1 : 2) < (1L << 31),
+                      "wgrad_group: problem %d: an operand of %ld rows exceeds 2 GiB", i, rows);
         tiles += (long)ceil_div(q.n, 128) * ceil_div(q.k, 128);
     }
     // K-slices: the count that minimises  rounds of workgroups x (K-tiles per slice + epilogue), in K-tile units -- a single
@@ -2349,6 +2381,7 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         P.ep.M = q.n;
         P.ep.N = q.k;
         P.ep.vec_ok = (q.k % 4 == 0) && aligned(q.gw, 16);
+        P.ep.vec8_ok = 0;
         P.ep.plain_acc = split == 1;
     }
     g.total = total;

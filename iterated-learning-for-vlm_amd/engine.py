@@ -24,6 +24,7 @@ import os
 import torch
 
 from . import ops
+from . import lib as _lib
 from .lib import (F32, BF16, ACT_QUICKGELU, ACT_GELU_ERF, ACT_QUICKGELU_BWD, ACT_GELU_ERF_BWD, POOL_MAX, POOL_MEAN,
                   POOL_SUM)
 
@@ -247,6 +248,15 @@ class PackedWeights:
         return (self.bwd if backward else self.fwd)[o:o + n]
 
 
+class TowerSaved:
+    """what ilvlm_tower_fwd leaves for the backward: the tower input, the block outputs [n, M, E] and the per-block saved
+    activations (n x stride bytes)"""
+    __slots__ = ("x0", "xs", "ws", "stride")
+
+    def __init__(self, x0, xs, ws, stride):
+        self.x0, self.xs, self.ws, self.stride = x0, xs, ws, stride
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -276,6 +286,8 @@ class Engine:
         self._wg = {}
         self._wg_keep = {}      # tower stream -> tensors its companion stream still reads
         self.composite = os.environ.get("ILVLM_COMPOSITE", "1") == "1"    # one C call per transformer block
+        self.tower_calls = os.environ.get("ILVLM_TOWER", "1") == "1"      # ... and one per TOWER in training steps (host time)
+        self.tower_count = [0, 0]         # tower forward / backward calls issued (tests)
         self.fused_fdt = os.environ.get("ILVLM_FUSED_FDT", "1") == "1"    # codebook scores + token max-pool in one GEMM
         self.trust_shadow = os.environ.get("ILVLM_TRUST_SHADOW", "1") == "1"
         self.defer_ln = os.environ.get("ILVLM_DEFER_LN", "1") == "1"      # one LayerNorm-gradient reduction per tower
@@ -610,6 +622,80 @@ class Engine:
                           M, E, dres=dmid, dx_f32=din, dx_lp=din_lp)
         return din, din_lp
 
+    # ------------------------------------------------------------------ whole towers in one C call (training steps)
+    def _tower_descs(self, fmt, n, E, H, causal):
+        """block descriptors of a tower, or None when any block is outside the composite path"""
+        if not (self.tower_calls and self.composite and not self.join_each_block):
+            return None
+        descs = [self._block_desc(fmt % i, E, H, causal) for i in range(n)]
+        return None if any(d is None for d in descs) else descs
+
+    def tower_fwd(self, x0, fmt, n, B, L, H, causal, seq=None):
+        """all n blocks of a tower through ilvlm_tower_fwd.  Returns (x_out, saved) or None when the tower path does not apply
+        (then the caller walks the blocks itself).  The activations of the whole tower are two allocations: the block outputs
+        xs [n, M, E] fp32 and the per-block workspaces n x stride bytes."""
+        M, E = x0.shape
+        descs = self._tower_descs(fmt, n, E, H, causal)
+        if descs is None:
+            return None
+        stride = max(ops.block_saved_bytes(d, M, B, L) for d in descs)
+        xs = torch.empty((n, M, E), dtype=torch.float32, device=x0.device)
+        ws = torch.empty(n * stride, dtype=torch.uint8, device=x0.device)
+        ops.tower_fwd(descs, x0, xs, ws, stride, B, L, seq)
+        self.tower_count[0] += 1
+        return xs[n - 1], TowerSaved(x0, xs, ws, stride)
+
+    def tower_bwd(self, ts, fmt, n, dx_f32, dx_lp, B, L, H, causal, seq=None, st=None):
+        """backward of tower_fwd's blocks through ilvlm_tower_bwd; returns the gradient pair of the tower input.  Per block:
+        the same arguments block_bwd would pass (which copies of the input gradient exist, the fp8 scale slots of the block
+        that consumes them, the LayerNorm slots), the gradients of all blocks in three allocations, one scratch allocation;
+        the per-block announcement (data-parallel reducer, in-backward optimizer) comes back through the `done` callback."""
+        x0, xs, ws, stride = ts.x0, ts.xs, ts.ws, ts.stride
+        M, E = x0.shape
+        descs = self._tower_descs(fmt, n, E, H, causal)
+        if descs is None:
+            raise RuntimeError("tower_bwd: the forward used the tower call, the backward cannot (composite path switched off in between?)")
+        dev = x0.device
+        lp = self.T != torch.float32
+        f8 = self.fp8 if (self.fp8 is not None and self.fp8.active) else None
+        sstride = max(ops.block_scratch_bytes(d, M) for d in descs)
+        d_f32 = torch.empty((n, M, E), dtype=torch.float32, device=dev)
+        d_lp = torch.empty((n, M, E), dtype=self.T, device=dev) if lp else None
+        d8 = torch.empty((n, M, E), dtype=torch.uint8, device=dev) if f8 is not None else None
+        scratch = torch.empty(n * sstride, dtype=torch.uint8, device=dev)
+        per = (_lib.TowerGrad * n)()
+        lnws = None if st is not None else ops._ln_workspace(dev, E)
+        trainable = [all(self.req[(fmt % i) + w] for w in Fp8State.WNAME.values()) for i in range(n)]
+        for i in range(n):
+            g = per[i]
+            # fp8 weight gradients on: a consumer block whose four weight matrices are trainable reads only the e5m2 copy of
+            # this block's input gradient, so the bf16 copy is not produced (block_bwd's `only8`)
+            only8 = f8 is not None and self.fp8_wgrad and i > 0 and trainable[i] and trainable[i - 1]
+            g.din_lp = d_lp[i].data_ptr() if (lp and not only8) else None
+            if f8 is not None and i > 0:
+                sc8, _, am8 = f8.s((fmt % (i - 1)) + "dout")
+                g.din8, g.din8_scale, g.din8_amax = d8[i].data_ptr(), sc8.data_ptr(), am8.data_ptr()
+            if st is not None:
+                g.ln_ws, g.ln_ws_blocks = st[0][i].data_ptr(), -ops.LN_WS_BLOCKS
+            else:
+                g.ln_ws, g.ln_ws_blocks = lnws.data_ptr(), ops.LN_WS_BLOCKS
+        slab = self._slab_ws()
+        for d in descs:
+            if slab is not None:
+                d.splitk_ws, d.splitk_ws_bytes = slab[0].data_ptr(), slab[0].numel()
+                d.splitk_cnt, d.splitk_cnt_len = slab[1].data_ptr(), slab[1].numel()
+            else:
+                d.splitk_ws, d.splitk_cnt = None, None
+        wg = self._wgrad_stream()
+        if wg is not None:      # operands of the weight-gradient GEMMs: alive until the join
+            self._wg_keep.setdefault(torch.cuda.current_stream().cuda_stream, []).extend(
+                [scratch, d_f32, d_lp, d8, dx_lp if lp else dx_f32, xs, ws])
+        need_cb = self.m._grad_sync is not None or getattr(self.arena, "eager_opt", None) is not None
+        ops.tower_bwd(descs, per, x0, xs, ws, stride, dx_f32, dx_lp if lp else None, d_f32, scratch, sstride, B, L, seq, wg,
+                      done=(lambda i: self.m._sync(fmt % i)) if need_cb else None)
+        self.tower_count[1] += 1
+        return d_f32[0], (d_lp[0] if lp else None)
+
     # ------------------------------------------------------------------ vision tower
     def vision_fwd(self, images, save):
         cfg, Wf, T = self.cfg, self.Wf, self.T
@@ -636,10 +722,14 @@ class Engine:
         x = _empty((B * Lv, W), torch.float32, images)
         mean0 = _empty((B * Lv,), torch.float32, images); rstd0 = torch.empty_like(mean0)
         ops.layernorm_fwd(tokens, Wf["visual.ln_pre.weight"], Wf["visual.ln_pre.bias"], x, mean0, rstd0, B * Lv, W)
-        blocks = []
-        for i in range(cfg["v_layers"]):
-            x, s = self.block_fwd(x, "visual.transformer.resblocks.%d." % i, B, Lv, cfg["v_heads"], 0, save)
-            blocks.append(s)
+        tw = self.tower_fwd(x, "visual.transformer.resblocks.%d.", cfg["v_layers"], B, Lv, cfg["v_heads"], 0) if save else None
+        if tw is not None:
+            x, blocks = tw
+        else:
+            blocks = []
+            for i in range(cfg["v_layers"]):
+                x, s = self.block_fwd(x, "visual.transformer.resblocks.%d." % i, B, Lv, cfg["v_heads"], 0, save)
+                blocks.append(s)
         saved = dict(B=B, P=P, Lv=Lv, W=W, patches=patches if self.req["visual.conv1.weight"] else None, tokens=tokens,
                      mean0=mean0, rstd0=rstd0, blocks=blocks) if save else None
         return x, saved     # x: final residual stream [B*Lv, W] fp32 (dense patch tokens are rows 1.. of each image)
@@ -647,11 +737,15 @@ class Engine:
     def vision_bwd(self, saved, dx_f32, dx_lp):
         cfg, Wf, Gr = self.cfg, self.Wf, self.Gr
         B, Lv, W = saved["B"], saved["Lv"], saved["W"]
-        composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
+        tower = isinstance(saved["blocks"], TowerSaved)
+        composite = tower or all(s is not None and len(s) == 2 for s in saved["blocks"])
         st = self._ln_defer_begin("v", cfg["v_layers"], W) if composite and all(
             self.req["visual.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["v_layers"])) else None
         carry = None
-        for i in reversed(range(cfg["v_layers"])):
+        if tower:
+            dx_f32, dx_lp = self.tower_bwd(saved["blocks"], "visual.transformer.resblocks.%d.", cfg["v_layers"], dx_f32, dx_lp, B, Lv,
+                                           cfg["v_heads"], 0, None, st)
+        for i in (() if tower else reversed(range(cfg["v_layers"]))):
             self._f8_carry = None
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "visual.transformer.resblocks.%d." % i, dx_f32, dx_lp, B, Lv,
                                            cfg["v_heads"], 0, ln_slots=st[0][i] if st is not None else None, f8_in=carry,
@@ -720,21 +814,29 @@ class Engine:
             raise RuntimeError("packed text rows: descriptor is for [%d,%d], tokens are [%d,%d]" % (seq.B, seq.ctx, B, Lt))
         x = _empty((seq.rows if seq is not None else B * Lt, Wt), torch.float32, table)
         ops.embed_fwd(tokens, table, Wf["encode_text.positional_embedding"], x, seq)
-        blocks = []
-        for i in range(cfg["t_layers"]):
-            x, s = self.block_fwd(x, "encode_text.transformer.resblocks.%d." % i, B, Lt, cfg["t_heads"], 1, save, seq)
-            blocks.append(s)
+        tw = self.tower_fwd(x, "encode_text.transformer.resblocks.%d.", cfg["t_layers"], B, Lt, cfg["t_heads"], 1, seq) if save else None
+        if tw is not None:
+            x, blocks = tw
+        else:
+            blocks = []
+            for i in range(cfg["t_layers"]):
+                x, s = self.block_fwd(x, "encode_text.transformer.resblocks.%d." % i, B, Lt, cfg["t_heads"], 1, save, seq)
+                blocks.append(s)
         saved = dict(B=B, Lt=Lt, Wt=Wt, tokens=tokens, blocks=blocks, seq=seq) if save else None
         return x, saved       # final residual stream BEFORE ln_final
 
     def text_bwd(self, saved, dx_f32, dx_lp):
         cfg, Gr = self.cfg, self.Gr
         B, Lt = saved["B"], saved["Lt"]
-        composite = all(s is not None and len(s) == 2 for s in saved["blocks"])
+        tower = isinstance(saved["blocks"], TowerSaved)
+        composite = tower or all(s is not None and len(s) == 2 for s in saved["blocks"])
         st = self._ln_defer_begin("t", cfg["t_layers"], saved["Wt"]) if composite and all(
             self.req["encode_text.transformer.resblocks.%d.ln_1.weight" % i] for i in range(cfg["t_layers"])) else None
         carry = None
-        for i in reversed(range(cfg["t_layers"])):
+        if tower:
+            dx_f32, dx_lp = self.tower_bwd(saved["blocks"], "encode_text.transformer.resblocks.%d.", cfg["t_layers"], dx_f32, dx_lp, B,
+                                           Lt, cfg["t_heads"], 1, saved["seq"], st)
+        for i in (() if tower else reversed(range(cfg["t_layers"]))):
             self._f8_carry = None
             dx_f32, dx_lp = self.block_bwd(saved["blocks"][i], "encode_text.transformer.resblocks.%d." % i, dx_f32, dx_lp, B,
                                            Lt, cfg["t_heads"], 1, saved["seq"], ln_slots=st[0][i] if st is not None else None,

@@ -36,6 +36,15 @@ class Block(C.Structure):
                 [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")])
 
 
+class TowerGrad(C.Structure):
+    """ilvlm_tower_grad: where block i of a tower call puts the copies of its input gradient, and its LayerNorm workspace"""
+    _fields_ = [("din_lp", vp), ("din8", vp), ("din8_scale", vp), ("din8_amax", vp), ("ln_ws", vp), ("ln_ws_blocks", i32),
+                ("pad_", i32)]
+
+
+BLOCK_DONE_FN = C.CFUNCTYPE(None, i32, vp)
+
+
 class WgradProblem(C.Structure):
     """ilvlm_wgrad_problem: one gw[n, k] += dy^T x (gb[n] += column sums of dy) of a grouped weight-gradient launch"""
     _fields_ = [("dy", vp), ("x", vp), ("gw", vp), ("gb", vp), ("n", i32), ("k", i32), ("inv_g", vp), ("inv_x", vp)]
@@ -101,11 +110,15 @@ SIGNATURES = {
     "ilvlm_sumsq": [vp, i64, vp, vp, vp],
     "ilvlm_clip_by_norm": [vp, i64, vp, f32, vp],
     "ilvlm_adamw_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
+    "ilvlm_adamw_step_packed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(AdamWHyper), vp],
     "ilvlm_selftest_fragments": [vp, vp],
     "ilvlm_block_saved_bytes": [C.POINTER(Block), i64, i32, i32],
     "ilvlm_block_scratch_bytes": [C.POINTER(Block), i64],
     "ilvlm_block_fwd": [C.POINTER(Block), vp, vp, vp, i64, i32, i32, i32, vp, vp],
     "ilvlm_block_bwd": [C.POINTER(Block), vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp],
+    "ilvlm_tower_fwd": [C.POINTER(Block), i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
+    "ilvlm_tower_bwd": [C.POINTER(Block), i32, C.POINTER(TowerGrad), vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, i32,
+                        vp, vp, BLOCK_DONE_FN, vp],
     "ilvlm_embed_packed_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_embed_packed_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ilvlm_attention_packed_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],

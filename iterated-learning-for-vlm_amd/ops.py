@@ -456,6 +456,47 @@ def block_bwd(desc, x_in, saved, dx_f32, dx_lp, din_f32, din_lp, scratch, B, Lq,
                                      _p(din8_scale), _p(din8_amax)), "block_bwd")
 
 
+def tower_fwd(descs, x0, xs, saved, saved_stride, B, Lq, seq=None):
+    """ilvlm_tower_fwd: all blocks of a tower in one call; xs [n, rows, E] receives the block outputs, saved n x saved_stride bytes"""
+    n, rows, E = xs.shape
+    _chk(x0, "tower.x0", torch.float32, (rows, E)); _chk(xs, "tower.xs", torch.float32); _chk(saved, "tower.saved", torch.uint8)
+    if len(descs) != n or saved.numel() < n * saved_stride:
+        raise RuntimeError("tower_fwd: %d descriptors for %d blocks / saved buffer too small" % (len(descs), n))
+    arr = (L.Block * n)(*descs)
+    L.check(L.load().ilvlm_tower_fwd(arr, n, x0.data_ptr(), xs.data_ptr(), saved.data_ptr(), saved_stride, rows, B, Lq,
+                                     seq.cap if seq is not None else Lq, seq.offs.data_ptr() if seq is not None else None,
+                                     _stream()), "tower_fwd")
+
+
+def tower_bwd(descs, per_block, x0, xs, saved, saved_stride, dtop_f32, dtop_lp, d_f32, scratch, scratch_stride, B, Lq, seq=None,
+              wgrad_stream=None, done=None):
+    """ilvlm_tower_bwd.  per_block: (lib.TowerGrad * n) filled by the caller; done(i): host callback after block i's backward
+    has been enqueued (an exception it raises is re-raised here, after the call has returned)."""
+    n, rows, E = xs.shape
+    _chk(dtop_f32, "tower.dtop", torch.float32, (rows, E)); _chk(d_f32, "tower.d", torch.float32, (n, rows, E))
+    _chk(scratch, "tower.scratch", torch.uint8); _chk(saved, "tower.saved", torch.uint8)
+    if len(descs) != n or scratch.numel() < n * scratch_stride or saved.numel() < n * saved_stride:
+        raise RuntimeError("tower_bwd: descriptor count / buffer sizes do not match %d blocks" % n)
+    arr = (L.Block * n)(*descs)
+    failure = []
+
+    def _cb(i, _user):
+        if failure:
+            return
+        try:
+            done(i)
+        except BaseException as exc:      # a ctypes callback cannot propagate: keep it and re-raise below
+            failure.append(exc)
+    cb = L.BLOCK_DONE_FN(_cb) if done is not None else L.BLOCK_DONE_FN()
+    rc = L.load().ilvlm_tower_bwd(arr, n, per_block, x0.data_ptr(), xs.data_ptr(), saved.data_ptr(), saved_stride,
+                                  dtop_f32.data_ptr(), _p(dtop_lp), d_f32.data_ptr(), scratch.data_ptr(), scratch_stride, rows, B, Lq,
+                                  seq.cap if seq is not None else Lq, seq.offs.data_ptr() if seq is not None else None, _WGRAD_TARGET,
+                                  _stream(), None if wgrad_stream is None else wgrad_stream.cuda_stream, cb, None)
+    if failure:
+        raise failure[0]
+    L.check(rc, "tower_bwd")
+
+
 class PackedSeq(object):
     """Row layout of a packed text batch (include/ilvlm_hip.h, "packed text rows"): sequence b owns rows
     [offs[b], offs[b+1]).  `lengths` is a host-side int sequence; the offsets live on the device as int32."""

@@ -23,6 +23,7 @@ class _StepFn(torch.autograd.Function):
         ctx.model, ctx.saved, ctx.n = model, saved, len(params)
         f8 = model._eng.fp8
         ctx.fp8_active = None if f8 is None else f8.active     # the saved buffers have THIS mode's layout
+        ctx.fp8_steps = None if f8 is None else f8.steps       # ... and were quantised with THIS step's scales
         return li, lt
 
     @staticmethod
@@ -37,6 +38,14 @@ class _StepFn(torch.autograd.Function):
         if f8 is None:
             ctx.model._backward_impl(saved, dli, dlt)
         else:
+            # The saved e4m3 activation copies and the fp8 weight copies are de-quantised with the scales the state holds NOW.
+            # A later TRAINING forward has rewritten them (and re-quantised the weights in place): this backward would produce
+            # silently wrong gradients.  The reference's loop (one forward, one backward) never does that; refuse rather than
+            # guess.  (Inference forwards in between are fine: they advance nothing.)
+            if ctx.fp8_active and f8.steps != ctx.fp8_steps:
+                raise RuntimeError("ilvlm fp8: backward of training forward #%d after training forward #%d has replaced its delayed "
+                                   "scales and fp8 weight copies; run each backward before the next training forward (or use "
+                                   "precision bf16 for multi-forward schemes)" % (ctx.fp8_steps, f8.steps))
             # run the backward in the fp8 mode of ITS forward (another forward may have switched the state since)
             now, f8.active = f8.active, ctx.fp8_active
             try:

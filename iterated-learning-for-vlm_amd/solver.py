@@ -368,7 +368,14 @@ class ClsSolver:
         elif gc.type == "logit_scale_param_abs_min":
             ops.clamp_(ls.data, gc.value, float("inf"))
         elif gc.type == "constant":
-            ls.requires_grad = False
+            # The reference sets requires_grad = False HERE, between forward and backward (train_solver.py:374-375).  In its
+            # first step the autograd graph of the forward already holds logit_scale as a leaf that requires a gradient, so
+            # that step still updates it once; from the second step on it is frozen.  The engine decides what to differentiate
+            # at backward time, so the flag is flipped after the first step's update to give the same trajectory.
+            if getattr(self, "_ls_const_frozen", False):
+                ls.requires_grad = False
+            else:
+                self._ls_freeze_after_step = True
         elif gc.type == "logit_scale_param":
             self._ls_before = ls.data.clone()                       # the reference reads .item() here: a host sync per step
         elif gc.type not in self.GRAD_CLIPS and gc.type != "logit_scale_param_ema":
@@ -385,6 +392,9 @@ class ClsSolver:
         elif gc.type == "logit_scale_param":
             # after - before > value -> before + value; before - after > value -> before - value: a clamp around `before`
             ls.data.copy_(torch.minimum(torch.maximum(ls.data, self._ls_before - gc.value), self._ls_before + gc.value))
+        elif gc.type == "constant" and getattr(self, "_ls_freeze_after_step", False):
+            ls.requires_grad = False                  # frozen from the second step on (see _param_clip_before)
+            self._ls_freeze_after_step, self._ls_const_frozen = False, True
 
     def _grad_clip_before(self):
         """between backward and optimizer.step() (train_solver.py:402-411, 431), on the flat gradient arena"""
@@ -411,8 +421,10 @@ class ClsSolver:
             return
         ls = self.model.module.logit_scale
         if getattr(self, "_ema_buf", None) is None:
-            self._ema_buf = torch.full_like(ls.data, 3.125)
-            self.clip_number = torch.zeros((), dtype=torch.int64, device=ls.device)
+            extra = self.state.get("solver_extra") or {}             # resumed run: continue the running mean and the count
+            self._ema_buf = (extra["ema_logit_scale"].to(ls.device).to(ls.dtype).reshape(ls.shape).clone()
+                             if "ema_logit_scale" in extra else torch.full_like(ls.data, 3.125))
+            self.clip_number = torch.full((), int(extra.get("clip_number", 0)), dtype=torch.int64, device=ls.device)
         lo, hi = self._ema_buf - gc.value, self._ema_buf + gc.value
         self.clip_number += ((ls.data > hi) | (ls.data < lo)).sum()
         ls.data.copy_(torch.minimum(torch.maximum(ls.data, lo), hi))
@@ -452,6 +464,15 @@ class ClsSolver:
             self.state["model"] = self.model.state_dict()
             self.state["optimizer"] = self.optimizer.state_dict()
             self.state["last_iter"] = curr_step
+            # solver-side state of grad_clip.type = logit_scale_param_ema / constant (an extra key: the reference keeps neither, so
+            # its EMA restarts at 3.125 on resume; files stay loadable by the reference, which reads the three keys above)
+            extra = {}
+            if getattr(self, "_ema_buf", None) is not None:
+                extra.update(ema_logit_scale=self._ema_buf.detach().cpu().clone(), clip_number=int(self.clip_number))
+            if getattr(self, "_ls_const_frozen", False):
+                extra["logit_scale_frozen"] = True
+            if extra:
+                self.state["solver_extra"] = extra
             paths = [os.path.join(self.save_path, name)]
             if curr_step % (self.config.saver.save_freq * 10) == 0:
                 k_path = self.save_path + "_k_times"

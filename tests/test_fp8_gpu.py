@@ -406,6 +406,18 @@ def test_fp8_state_is_not_advanced_by_inference_forwards():
     gb = mb.visual.transformer.resblocks[0].mlp.c_fc.weight.grad
     # (split-K fp32 atomics: equal up to the summation order)
     assert float((g_old - gb).abs().max()) <= 1e-3 * float(gb.abs().max()), "observe-mode backward must equal the bf16 one"
+    # advisor finding (round 3): two ACTIVE training forwards before the first backward -- the second one rewrites the delayed
+    # scales and re-quantises the weights in place, so the first forward's saved fp8 copies can no longer be de-quantised:
+    # refused loudly instead of producing silently wrong gradients; the latest forward's own backward is fine
+    loss3, _ = ClipInfoCELoss()(li3, lt3)
+    (li4, lt4), _ = m(img, texts)
+    with pytest.raises(RuntimeError, match="replaced its delayed scales"):
+        loss3.backward()
+    loss4, _ = ClipInfoCELoss()(li4, lt4)
+    m.zero_grad()
+    loss4.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.visual.transformer.resblocks[0].mlp.c_fc.weight.grad).all())
 
 
 def test_fp8_loss_curve_tracks_bf16_at_real_size():

@@ -315,6 +315,41 @@ def test_composite_block_calls_equal_the_kernel_by_kernel_path(golden_dir, preci
         assert float((outs[0][2][n] - gr).abs().max()) / scale < 1e-4 or float((outs[0][2][n] - gr).abs().max()) < 1e-7, n
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp8"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_tower_calls_equal_the_block_by_block_path(golden_dir, precision, packed):
+    """ilvlm_tower_fwd / _bwd walk the blocks of a tower through the very block entry points the engine otherwise calls one by
+    one (activations, gradients and scratch of all blocks in a few big buffers instead of per-block allocations): logits
+    bit-identical, gradients equal up to the summation order of the split-K atomics -- in fp32, bf16 and fp8 mode (second
+    step: delayed scales in use, e5m2 gradient copies handed from block to block), dense and packed text rows."""
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    g = np.load(os.path.join(golden_dir, "g1_fdt_step_a.npz"))
+    img = torch.from_numpy(g["images"]).cuda()
+    tok, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["pad_mask"])
+    lens = [int(v) for v in (mask == 0).sum(1)]
+    texts = (tok, mask, lens) if packed else (tok.cuda(), mask.cuda())
+    v = FDT_VARIANTS[0]
+    outs = []
+    for tower in (True, False):
+        model = build("a", v, precision)
+        model.engine.tower_calls = tower
+        for _ in range(2 if precision == "fp8" else 1):
+            (li, lt), _ = model(img, texts)
+            loss, _ = ClipInfoCELoss()(li, lt)
+            model.zero_grad()
+            loss.backward()
+        torch.cuda.synchronize()
+        steps = 2 if precision == "fp8" else 1
+        assert model.engine.tower_count == ([2 * steps, 2 * steps] if tower else [0, 0])      # the path under test was really taken
+        outs.append((li.detach().cpu(), lt.detach().cpu(), {n: p.grad.detach().float().cpu().clone()
+                                                             for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert set(outs[0][2]) == set(outs[1][2])
+    for n, gr in outs[1][2].items():
+        scale = max(float(gr.abs().max()), 1e-12)
+        assert float((outs[0][2][n] - gr).abs().max()) / scale < 1e-4 or float((outs[0][2][n] - gr).abs().max()) < 1e-7, n
+
+
 def test_real_size_vitb32_fdt_step_matches_oracle_fp32():
     """The shipped geometry (ViT-B/32, 12 + 12 layers, 4096 x 512 codebook) at batch 16 in fp32 mode: logits, loss and a
     sample of gradients (one per kind of kernel that produces them) against the CPU oracle on the same random weights --

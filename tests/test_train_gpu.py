@@ -614,12 +614,30 @@ def test_every_grad_clip_type_of_the_reference(gtype, tmp_path):
             assert abs(float(ls1 - ls0)) <= value * (1 + 1e-6) and abs(float(ls1 - ls0)) > 0.5 * value
         elif gtype == "logit_scale_param_abs_min":
             assert float(ls1) >= float(np.float32(value))
-        elif gtype == "constant":       # (the reference flips the flag after its first forward, so ITS first step still moves the
-            assert torch.equal(ls1, ls0) and not m.logit_scale.requires_grad    # scalar once; here it is frozen from step one)
+        elif gtype == "constant":
+            # the reference flips requires_grad between its first forward and backward: the graph of that forward still holds
+            # the scalar as a leaf, so step 1 moves it once and every later step leaves it alone -- the same trajectory here
+            if step == 1:
+                assert not torch.equal(ls1, ls0)
+            else:
+                assert torch.equal(ls1, ls0)
+            assert not m.logit_scale.requires_grad
     if gtype == "logit_scale_param_ema":
         # ln(1/0.07) = 2.659 starts 0.466 away from the 3.125 the running mean starts at: clamped to within 0.05 of it each step
         assert 1 <= int(sol.clip_number) <= 3
         assert abs(float(m.logit_scale.detach()) - float(sol._ema_buf)) <= 0.05 / 0.9 + 1e-6
+        # the running mean and the count travel with the checkpoint (the reference restarts both on resume)
+        os.environ["ILVLM_ASYNC_CKPT"] = "0"
+        try:
+            sol.save_checkpoint(3)
+        finally:
+            del os.environ["ILVLM_ASYNC_CKPT"]
+        extra = sol.state["solver_extra"]
+        assert float(extra["ema_logit_scale"]) == float(sol._ema_buf) and extra["clip_number"] == int(sol.clip_number)
+        ema, cnt = float(sol._ema_buf), int(sol.clip_number)
+        sol._ema_buf = None
+        sol._ema_clip()                  # first call of a resumed run picks them up from the loaded state
+        assert int(sol.clip_number) >= cnt and abs(float(sol._ema_buf) - (0.9 * ema + 0.1 * float(m.logit_scale.detach()))) < 1e-6
     with pytest.raises(NotImplementedError):
         bad = _clip_solver(tmp_path, dict(type="no_such_clip", value=1.0, max_value=6))
         bad.train_step(image, text, 1)
