@@ -220,6 +220,7 @@ def main():
                                                      amsgrad=False, eps=1e-8)))
     sched = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=opt, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                             warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
+    opt.prezero_grads = os.environ.get("ILVLM_PREZERO", "1") == "1"      # as the solver does (solver.build_optimizer)
     if args.overlap_adamw:
         # reference order (zero_grad, one backward, step): each block's AdamW goes out as soon as its gradients are final
         opt.overlap_backward(True)
@@ -341,7 +342,7 @@ def main():
         attn_flops = 7 * 2.0 * 64 * (args.batch * v_tok * v_tok * v_heads * v_layers + text_l2 * t_heads * t_layers)
         executed_flops = s["flops"] / nprof + s["f32_flops"] / nprof + attn_flops
         traffic, traffic_src = None, None      # HBM-side bytes per launch of this kernel family from the committed PMC passes
-        for rnd in ("round3", "round2", "round1"):
+        for rnd in ("round4", "round3", "round2", "round1"):
             try:
                 if args.model != "vitb32":
                     break
@@ -417,6 +418,7 @@ def main():
                                                        betas=[0.9, 0.98], amsgrad=False, eps=1e-8)))
         sc = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=o, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                              warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
+        o.prezero_grads = os.environ.get("ILVLM_PREZERO", "1") == "1"
         dd.train()
         im, tk, pd, ln = synthetic_batch(batch, rank, dev)
         tx = (tk, pd, ops.PackedSeq(ln, tk.shape[1], dev))

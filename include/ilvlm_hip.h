@@ -310,6 +310,33 @@ int ilvlm_fp8_scale_update(float* amax_cur, float* hist, float* scale, float* in
 int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, const unsigned char* flags, float* dst, int B, int H, int W,
                              const float* mean3, const float* std3, void* stream);
 
+/* ---- input pipeline, the random augmentations: MOCOV2_single of prototype/data/imagenet_dataloader.py:59-68
+ * (RandomResizedCrop, ColorJitter @ 0.8, RandomGrayscale, GaussianBlur @ 0.5, RandomHorizontalFlip, ToTensor, Normalize) from
+ * DECODED uint8 images of any size.  The random draws are made on the host (what torchvision's get_params return, one
+ * ilvlm_augment_params per sample); the pixel work -- antialiased bilinear resize of the crop box to out_size x out_size, the
+ * four colour operations in the drawn order with PIL's integer luma / blend / HSV arithmetic, luma replacement, separable
+ * Gaussian blur, flip, normalise -- runs on the device.  src: the images back to back as [H][W][3] uint8, image b at byte
+ * src_offsets[b] with src_hw[2b], src_hw[2b+1] = its height, width (device arrays; the crop box must lie inside the image);
+ * dst: fp32 [B,3,out_size,out_size]; scratch: ilvlm_image_augment_scratch_floats(B, out_size, max_crop_rows) floats, where
+ * max_crop_rows >= every crop_h; mean3 / std3: HOST arrays.  Differences from PIL that remain (fp32 resampling and a true
+ * Gaussian instead of 8-bit fixed point and box-blur passes): csrc/augment.hip; tests/test_input_pipeline_gpu.py. */
+typedef struct ilvlm_augment_params {
+    int crop_top, crop_left, crop_h, crop_w; /* RandomResizedCrop.get_params */
+    int jitter;                              /* ColorJitter applied (RandomApply, p = 0.8) */
+    int jitter_order;                        /* its four operations in application order, 2 bits each from bit 0:
+                                                0 brightness, 1 contrast, 2 saturation, 3 hue (torch.randperm(4)) */
+    float brightness, contrast, saturation;  /* factors, U(0.6, 1.4) for the shipped 0.4 */
+    float hue;                               /* U(-0.1, 0.1) */
+    int grayscale;                           /* RandomGrayscale (p = 0.2) */
+    float blur_sigma;                        /* > 0: GaussianBlur with this sigma (p = 0.5, U(0.1, 2.0)); 0: none */
+    int flip;                                /* RandomHorizontalFlip */
+    int pad_;
+} ilvlm_augment_params;
+long ilvlm_image_augment_scratch_floats(int B, int out_size, int max_crop_rows);
+int ilvlm_image_augment(const unsigned char* src, const long* src_offsets, const int32_t* src_hw, const ilvlm_augment_params* params,
+                        float* dst, float* scratch, int B, int out_size, int max_crop_rows, const float* mean3, const float* std3,
+                        void* stream);
+
 /* ---- small utilities ---- */
 /* out[c] += sum_r x[r,c]  (bias gradients) */
 int ilvlm_colsum(const void* x, int dtype, float* out, long rows, int cols, int ld, void* stream);

@@ -773,7 +773,17 @@ __device__ __forceinline__ void epilogue_acc_tile(const EpiArgs& ep, f32x4 (&acc
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (m_base + P * 32 < ep.M) {
+        if (PLAIN && ep.vec_ok && ep.e.out_group == 0 && m_base + P * 32 + 32 <= ep.M && n_base + 64 <= ep.N) {
+            // single writer, whole 32 x 64 slice: 16-byte load-add-store, 4 rows x 256 B per wave instruction -- 16 vector-memory
+            // instructions per pass instead of the 64 of the one-dword-per-lane form (the epilogue is bound by their number)
+#pragma unroll 2
+            for (int k = 0; k < 8; ++k) {
+                const int row = 4 * k + g;
+                float* dst = ep.Cf + (long)(m_base + P * 32 + row) * ep.ldc + n_base + 4 * c;
+                const f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
+                *(f32x4*)dst = *(const f32x4*)dst + v * alpha;
+            }
+        } else if (m_base + P * 32 < ep.M) {
 #pragma unroll 4
             for (int r = 0; r < 32; ++r) {
                 const int m = m_base + P * 32 + r;

@@ -52,6 +52,10 @@ class ParamArena:
         self.views, self.gviews, self.sviews = {}, {}, {}
         self.inactive = set()     # parameters the loss never reaches (no gradient, untouched by the optimizer)
         self.shadow_fresh = False # set by the fused optimizer: its kernel wrote the bf16 shadow of what it updated
+        self.packed_fresh = False # ... and the fragment-order images of the packed GEMM weights (ilvlm_adamw_step_packed)
+        self.packed = None        # engine.PackedWeights of this arena (bf16 mode), for the optimizer
+        self._prezero = None      # (event, G version) of a gradient memset issued ahead of zero_grad() (prezero_grads)
+        self._zstream = None
         self._versions = None
         self.reducer = None       # comm.GradReducer installed by the data-parallel wrapper
         self.eager_opt = None     # FusedAdamW.overlap_backward(): the optimizer that updates blocks from inside backward
@@ -94,7 +98,30 @@ class ParamArena:
             ops.cast_f32(self.P, self.S)
 
     def zero_grad(self):
+        ev = self._prezero
+        if ev is not None and self.G._version == ev[1]:
+            # the optimizer zeroed the arena on a side stream right after its update (FusedAdamW.prezero_grads) and nothing
+            # has written gradients through torch since: only order this stream behind that memset
+            torch.cuda.current_stream(self.G.device).wait_event(ev[0])
+            self._prezero = None
+            return
+        self._prezero = None
         self.G.zero_()
+
+    def prezero_grads(self):
+        """zero the gradient arena on a side stream, ordered after everything enqueued on the current stream (the optimizer's
+        update has read the gradients); the next zero_grad() waits for it instead of issuing its own memset.  Kernel writes
+        into the arena only happen in backward, which follows that zero_grad(); writes through torch bump G's version
+        counter and make zero_grad() fall back to its own memset."""
+        dev = self.G.device
+        if self._zstream is None:
+            self._zstream = torch.cuda.Stream(device=dev)
+        self._zstream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._zstream):
+            self.G.zero_()
+            ev = torch.cuda.Event()
+            ev.record(self._zstream)
+        self._prezero = (ev, self.G._version)
 
     def reducing(self):
         """True when a data-parallel wrapper exchanges gradients over ranks in this process (a world of one rank does not,
@@ -236,6 +263,7 @@ class PackedWeights:
                     for c0 in range(0, c, 64):
                         table.append((arena.offsets[name] // 64, r, c, r0, c0))
         self.table = torch.tensor(table, dtype=torch.int32).to(dev)
+        self.names = frozenset(pre + wn for pre in block_prefixes for wn in self.WNAME.values())
         self.fwd = torch.zeros(arena.total, dtype=torch.bfloat16, device=dev)
         self.bwd = torch.zeros(arena.total, dtype=torch.bfloat16, device=dev)
 
@@ -330,9 +358,12 @@ class Engine:
         # reference solver only does that to logit_scale, which the kernels read in fp32 -- so code that edits GEMM weights
         # that way calls mark_dirty() (or sets ILVLM_TRUST_SHADOW=0).
         vers = a.versions()
-        if not (self.trust_shadow and a.shadow_fresh and not swapped and vers == a._versions):
+        current = self.trust_shadow and a.shadow_fresh and not swapped and vers == a._versions
+        if not current:
             a.refresh_shadow()
-        a.shadow_fresh = False
+        # the fragment-order images are current under the same conditions when the optimizer wrote them with its update
+        packed_current = current and a.packed_fresh
+        a.shadow_fresh = a.packed_fresh = False
         a._versions = vers
         self.Wf = a.views                                     # fp32 masters
         self.Wc = a.views if self.precision == "fp32" else a.sviews   # GEMM operands
@@ -346,9 +377,11 @@ class Engine:
         if self.precision == "bf16" and self.use_packed:
             # the streaming GEMM kernel reads the block weights in fragment order: re-pack from the (now current) shadow
             if self.packed is None:
-                self.packed = PackedWeights(a, pres)
+                self.packed = a.packed = PackedWeights(a, pres)
                 self._blk = {}
-            self.packed.refresh()
+                packed_current = False
+            if not packed_current:
+                self.packed.refresh()
         req = {n: p.requires_grad for n, p in a.named}
         if req != getattr(self, "req", None):
             self._blk = {}                                    # frozen / unfrozen parameters: new gradient slots

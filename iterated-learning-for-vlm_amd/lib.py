@@ -36,6 +36,13 @@ class Block(C.Structure):
                 [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")])
 
 
+class AugmentParams(C.Structure):
+    """ilvlm_augment_params: the random draws of MOCOV2_single for one sample (made on the host)"""
+    _fields_ = [("crop_top", i32), ("crop_left", i32), ("crop_h", i32), ("crop_w", i32), ("jitter", i32), ("jitter_order", i32),
+                ("brightness", f32), ("contrast", f32), ("saturation", f32), ("hue", f32), ("grayscale", i32),
+                ("blur_sigma", f32), ("flip", i32), ("pad_", i32)]
+
+
 class TowerGrad(C.Structure):
     """ilvlm_tower_grad: where block i of a tower call puts the copies of its input gradient, and its LayerNorm workspace"""
     _fields_ = [("din_lp", vp), ("din8", vp), ("din8_scale", vp), ("din8_amax", vp), ("ln_ws", vp), ("ln_ws_blocks", i32),
@@ -100,6 +107,8 @@ SIGNATURES = {
     "ilvlm_fp8_quantize_weights": [vp, vp, vp, vp, i32, vp, vp, vp],
     "ilvlm_fp8_scale_update": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_image_u8_normalize": [vp, i32, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
+    "ilvlm_image_augment_scratch_floats": [i32, i32, i32],
+    "ilvlm_image_augment": [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
     "ilvlm_cast_f32": [vp, vp, i32, i64, vp],
     "ilvlm_cast_to_f32": [vp, i32, vp, i64, vp],
     "ilvlm_scale": [vp, vp, f32, i64, vp],
@@ -157,7 +166,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i64 if name.endswith("_bytes") else i32
+        fn.restype = i64 if name.endswith(("_bytes", "_floats")) else i32
     _lib = lib
     return lib
 

@@ -780,6 +780,74 @@ def image_u8_normalize(src, dst=None, flags=None, mean=IMAGENET_MEAN, std=IMAGEN
     return dst
 
 
+def mocov2_params(sizes, rng, out_size=224, scale=(0.2, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), jitter=(0.4, 0.4, 0.4, 0.1),
+                  p_jitter=0.8, p_gray=0.2, p_blur=0.5, sigma=(0.1, 2.0), p_flip=0.5):
+    """The random draws of MOCOV2_single (reference prototype/data/imagenet_dataloader.py:59-68) for a batch of decoded images
+    of the given (height, width) sizes, made on the host with `rng` (a random.Random): RandomResizedCrop.get_params (ten
+    attempts at an area / aspect draw, then the centre-crop fallback), RandomApply(ColorJitter) with ColorJitter.get_params
+    (a permutation of the four operations and U(1 - x, 1 + x) / U(-hue, hue) factors), RandomGrayscale, RandomApply(
+    GaussianBlur) with sigma ~ U(0.1, 2), RandomHorizontalFlip.  Returns a ctypes array of lib.AugmentParams."""
+    import math
+    arr = (L.AugmentParams * len(sizes))()
+    for a, (H, W) in zip(arr, sizes):
+        area = H * W
+        for _ in range(10):
+            target = area * rng.uniform(scale[0], scale[1])
+            ar = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1])))
+            w, h = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+            if 0 < w <= W and 0 < h <= H:
+                a.crop_top, a.crop_left, a.crop_h, a.crop_w = rng.randint(0, H - h), rng.randint(0, W - w), h, w
+                break
+        else:                                   # fallback: central crop at the nearest admissible aspect ratio
+            in_ratio = W / H
+            if in_ratio < ratio[0]:
+                w, h = W, int(round(W / ratio[0]))
+            elif in_ratio > ratio[1]:
+                h, w = H, int(round(H * ratio[1]))
+            else:
+                w, h = W, H
+            a.crop_top, a.crop_left, a.crop_h, a.crop_w = (H - h) // 2, (W - w) // 2, h, w
+        a.jitter = int(rng.random() < p_jitter)
+        order = [0, 1, 2, 3]
+        rng.shuffle(order)
+        a.jitter_order = order[0] | (order[1] << 2) | (order[2] << 4) | (order[3] << 6)
+        a.brightness = rng.uniform(max(0.0, 1 - jitter[0]), 1 + jitter[0])
+        a.contrast = rng.uniform(max(0.0, 1 - jitter[1]), 1 + jitter[1])
+        a.saturation = rng.uniform(max(0.0, 1 - jitter[2]), 1 + jitter[2])
+        a.hue = rng.uniform(-jitter[3], jitter[3])
+        a.grayscale = int(rng.random() < p_gray)
+        a.blur_sigma = rng.uniform(sigma[0], sigma[1]) if rng.random() < p_blur else 0.0
+        a.flip = int(rng.random() < p_flip)
+    return arr
+
+
+def image_augment(src, offsets, hw, params, out_size=224, dst=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """MOCOV2_single on the device (ilvlm_image_augment): src = the decoded uint8 images back to back ([H][W][3] each) on the
+    device, offsets int64 [B] (byte offset of each), hw int32 [B,2]; params: lib.AugmentParams array (mocov2_params) or a uint8
+    device tensor holding it.  Returns fp32 [B,3,out_size,out_size]."""
+    _chk(src, "augment.src", torch.uint8); _chk(offsets, "augment.offsets", torch.int64); _chk(hw, "augment.hw", torch.int32)
+    B = offsets.numel()
+    if tuple(hw.shape) != (B, 2):
+        raise RuntimeError("image_augment: hw must be int32 [B,2]")
+    if not torch.is_tensor(params):
+        if len(params) != B:
+            raise RuntimeError("image_augment: %d parameter records for %d images" % (len(params), B))
+        max_rows = max(p.crop_h for p in params)
+        params = torch.frombuffer(bytearray(bytes(params)), dtype=torch.uint8).to(src.device)
+    else:
+        _chk(params, "augment.params", torch.uint8, (B * C.sizeof(L.AugmentParams),))
+        max_rows = int(hw[:, 0].max())
+    if dst is None:
+        dst = torch.empty((B, 3, out_size, out_size), dtype=torch.float32, device=src.device)
+    _chk(dst, "augment.dst", torch.float32, (B, 3, out_size, out_size))
+    n = L.load().ilvlm_image_augment_scratch_floats(B, out_size, max_rows)
+    scratch = torch.empty(n, dtype=torch.float32, device=src.device)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(L.load().ilvlm_image_augment(src.data_ptr(), offsets.data_ptr(), hw.data_ptr(), params.data_ptr(), dst.data_ptr(),
+                                         scratch.data_ptr(), B, out_size, max_rows, m3, s3, _stream()), "image_augment")
+    return dst
+
+
 def cast_to_f32(src, dst):
     """dst (fp32) = src (bf16)"""
     _chk(src, "cast_to_f32.src", torch.bfloat16); _chk(dst, "cast_to_f32.dst", torch.float32)

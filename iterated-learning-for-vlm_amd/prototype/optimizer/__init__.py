@@ -3,6 +3,7 @@ multi-tensor HIP AdamW over the parameter arena; its param_groups / state / stat
 torch.optim.AdamW's layout ('step', 'exp_avg', 'exp_avg_sq') so reference checkpoints round-trip."""
 import bisect
 import ctypes as C
+import os
 
 import torch
 
@@ -27,6 +28,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ostreams = set()      # streams that carry in-backward updates of the current step
         self._eager = []            # chunk-index ranges already updated in the current backward
         self._ranges = {}           # block prefix -> [i0, i1) of the (offset-sorted) chunk table
+        self._tiles = None          # tile table of the GEMM weights kept in fragment order (ilvlm_adamw_step_packed)
+        # opt-in for loops in the reference's order (zero_grad right before the ONE backward of a step, nothing reading
+        # gradients between step() and zero_grad()): step() zeroes the gradient arena itself, on a side stream beside the
+        # next forward, and zero_grad() only waits for that -- the 0.11 ms memset leaves the critical path
+        self.prezero_grads = False
 
     # -- arena binding -----------------------------------------------------------------------
     def _bind(self):
@@ -53,14 +59,30 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _build_table(self):
         arena = self._arena
-        sig = tuple(tuple(bool(p.requires_grad) and (p._ilvlm_arena[1] not in arena.inactive) for p in g["params"])
-                    for g in self.param_groups)
+        sig = (tuple(tuple(bool(p.requires_grad) and (p._ilvlm_arena[1] not in arena.inactive) for p in g["params"])
+                     for g in self.param_groups), self._overlap, getattr(arena, "packed", None) is not None)
         if sig == self._sig:
             return
         offs, cnts, grps = [], [], []
+        # GEMM weights the engine keeps in MFMA-fragment order (bf16 mode): updated tile by tile by the kernel that also
+        # writes both packed images, so the per-step re-pack launch disappears.  Not with in-backward updates (their launches
+        # are slices of the chunk table) -- those keep the separate re-pack.
+        packed = getattr(arena, "packed", None)
+        tiled = packed.names if (packed is not None and not self._overlap and arena.S is not None and
+                                 os.environ.get("ILVLM_ADAMW_PACK", "1") == "1") else ()
+        tiles = []
         for gi, g in enumerate(self.param_groups):
-            for p, act in zip(g["params"], sig[gi]):
-                o, n = arena.offsets[p._ilvlm_arena[1]], p.numel()
+            for p, act in zip(g["params"], sig[0][gi]):
+                name = p._ilvlm_arena[1]
+                o, n = arena.offsets[name], p.numel()
+                if name in tiled:
+                    r, c = p.shape
+                    grp = gi if act else INACTIVE_GROUP
+                    tiles += [(o // 64, r, c, r0, c0, grp) for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+                    if act and p not in self.state:
+                        m, v = self._views(p)
+                        self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=m, exp_avg_sq=v)
+                    continue
                 for c in range(0, n, CHUNK):
                     offs.append(o + c)
                     cnts.append(min(CHUNK, n - c))
@@ -76,6 +98,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._coff = torch.tensor(offs, dtype=torch.int64, device=dev)
         self._ccnt = torch.tensor(cnts, dtype=torch.int32, device=dev)
         self._cgrp = torch.tensor(grps, dtype=torch.int32, device=dev)
+        self._tiles = torch.tensor(tiles, dtype=torch.int32, device=dev) if tiles else None
         self._sig = sig
         self._ranges = {}
 
@@ -192,6 +215,13 @@ class FusedAdamW(torch.optim.Optimizer):
             self._launch(cur, i0, h, st.cuda_stream)
             cur = max(cur, i1)
         self._launch(cur, len(self._offs_host), h, st.cuda_stream)
+        packed_done = False
+        if self._tiles is not None:
+            pk = arena.packed
+            L.check(L.load().ilvlm_adamw_step_packed(arena.P.data_ptr(), arena.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                     arena.S.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr(), self._tiles.data_ptr(),
+                                                     int(self._tiles.shape[0]), C.byref(h), st.cuda_stream), "adamw_step_packed")
+            packed_done = True
         if self._eager:
             for o in self._ostreams:
                 if o is not st:
@@ -199,6 +229,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self._ostreams.clear()
             self._eager = []
         arena.shadow_fresh = arena.S is not None       # the kernel wrote the bf16 shadow of every element it updated
+        arena.packed_fresh = packed_done               # ... and both fragment-order images of every packed weight it updated
+        if self.prezero_grads:
+            arena.prezero_grads()
 
     def state_dict(self):
         for st in self.state.values():

@@ -98,12 +98,39 @@ class DevicePrefetcher:
     Images may arrive as uint8 ([B,H,W,3] as decoders produce them, or [B,3,H,W]), alone or as (image_u8, flags) with
     per-sample uint8 flags (bit 0 horizontal flip, bit 1 grayscale): the batch then crosses PCIe at a quarter of the fp32
     size and ToTensor + Normalize (+ the flip / grayscale of MOCOV2_single) run on the device
-    (ops.image_u8_normalize; reference prototype/data/imagenet_dataloader.py:13-14,59-68)."""
+    (ops.image_u8_normalize; reference prototype/data/imagenet_dataloader.py:13-14,59-68).
+    A batch whose image part is a LIST of decoded uint8 [H,W,3] images of any sizes (what a loader yields when it stops after
+    decode) takes the whole MOCOV2_single augmentation on the device: the random draws are made here on the host
+    (ops.mocov2_params, seeded by `augment_seed` and the batch index), the images cross PCIe back to back in one pinned buffer,
+    and RandomResizedCrop / ColorJitter / RandomGrayscale / GaussianBlur / flip / ToTensor / Normalize run in
+    ops.image_augment on this prefetcher's stream, beside the step on the previous batch."""
 
-    def __init__(self, loader, tokenize, device, depth=2):
+    def __init__(self, loader, tokenize, device, depth=2, augment_seed=0, out_size=224):
         self.loader, self.tokenize, self.device, self.depth = loader, tokenize, torch.device(device), depth
         self.dataloader = self
         self.num_batches = getattr(loader, "num_batches", None)
+        self.augment_seed, self.out_size, self._batches = augment_seed, out_size, 0
+
+    def _augment(self, images):
+        """list of uint8 [H,W,3] CPU tensors -> fp32 [B,3,out,out] on the device (current stream)"""
+        import random
+        from . import ops
+        sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+        for im in images:
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                raise RuntimeError("DevicePrefetcher: decoded images must be uint8 [H,W,3], got %s %s" % (im.dtype, tuple(im.shape)))
+        params = ops.mocov2_params(sizes, random.Random((self.augment_seed << 32) ^ self._batches), out_size=self.out_size)
+        self._batches += 1
+        total = sum(h * w * 3 for h, w in sizes)
+        flat = torch.empty(total, dtype=torch.uint8).pin_memory()
+        offs, o = [], 0
+        for im, (h, w) in zip(images, sizes):
+            offs.append(o)
+            flat[o:o + h * w * 3].copy_(im.reshape(-1))
+            o += h * w * 3
+        dev = self.device
+        return ops.image_augment(flat.to(dev, non_blocking=True), torch.tensor(offs, dtype=torch.int64).pin_memory().to(dev, non_blocking=True),
+                                 torch.tensor(sizes, dtype=torch.int32).pin_memory().to(dev, non_blocking=True), params, self.out_size)
 
     def __len__(self):
         return len(self.loader)
@@ -118,8 +145,18 @@ class DevicePrefetcher:
             tokens, lengths, pad = self.tokenize(list(text), return_length=True)
             text = (tokens, pad, lengths.tolist())
         flags = None
-        if isinstance(image, (tuple, list)):
+        decoded = isinstance(image, (tuple, list)) and len(image) > 0 and all(torch.is_tensor(t) and t.dim() == 3 for t in image) and \
+            not (len(image) == 2 and image[1].dim() == 1)
+        if isinstance(image, (tuple, list)) and not decoded:
             image, flags = image
+        if cuda and decoded:
+            with torch.cuda.stream(stream):
+                image = self._augment(list(image))
+                if isinstance(text, tuple) and torch.is_tensor(text[0]):
+                    text = tuple(t.pin_memory().to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in text)
+                done = torch.cuda.Event()
+                done.record(stream)
+            return image, text, done
         if cuda:
             with torch.cuda.stream(stream):
                 image = (image if image.is_pinned() else image.pin_memory()).to(self.device, non_blocking=True)
@@ -301,6 +338,9 @@ class ClsSolver:
         kwargs = dict(oc.kwargs)
         kwargs["params"] = param_group_all(self.model, pconfig)[0]
         self.optimizer = optim_entry(dict(type=oc.type, kwargs=kwargs))
+        # the loop below calls zero_grad() right before the one backward of a step and nothing reads gradients after step():
+        # the optimizer may zero the arena itself, beside the next forward (ILVLM_PREZERO=0 restores the memset in zero_grad)
+        self.optimizer.prezero_grads = os.environ.get("ILVLM_PREZERO", "1") == "1"
         # train_step() below keeps the reference's order (zero_grad, one backward, step, nothing touching gradients in
         # between), which is what the in-backward update needs
         # (opt-in: on one GPU it measured +-0, the chip is already full during backward)

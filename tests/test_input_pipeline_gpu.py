@@ -61,3 +61,76 @@ def test_prefetcher_takes_uint8_batches():
         torch.cuda.synchronize()
         assert img.dtype == torch.float32 and img.shape == (4, 3, 32, 32) and img.is_cuda
         assert float((img.cpu() - cpu_pipeline(u8, flags.tolist())).abs().max()) < 1e-5
+
+
+from augment_ref import cpu_augment  # noqa: E402  (tests/augment_ref.py: the float restatement, pinned against PIL on the CPU)
+
+
+def test_mocov2_augmentations_on_the_device_match_the_float_cpu_pipeline():
+    """Every operation of MOCOV2_single after decode, with the random draws fixed: images of several sizes (up- and
+    down-scaling by the crop, a 4.6x reduction among them), all four colour operations in two different orders, grayscale,
+    a narrow and the widest blur, flips.  The kernels work in fp32 where the restatement works in fp64: almost every pixel
+    equal, none further than two 8-bit levels."""
+    import random
+    from ilvlm_amd import ops, lib as L
+    OUT = 224
+    rng = np.random.RandomState(7)
+    sizes = [(300, 400), (48, 64), (1100, 900), (224, 224), (500, 333), (260, 260)]
+    imgs = []
+    for (H, W) in sizes:          # smooth structure + noise, so that resampling and blur have something to act on
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = np.stack([128 + 100 * np.sin(xx / 17.0 + c) * np.cos(yy / 23.0 - c) for c in range(3)], -1)
+        imgs.append(np.clip(base + rng.randn(H, W, 3) * 20, 0, 255).astype(np.uint8))
+    params = ops.mocov2_params(sizes, random.Random(3))
+    # fix the draws so that every branch is exercised somewhere
+    orders = [0 | (1 << 2) | (2 << 4) | (3 << 6), 3 | (2 << 2) | (1 << 4) | (0 << 6), 1 | (3 << 2) | (0 << 4) | (2 << 6)]
+    for i, p in enumerate(params):
+        p.jitter, p.jitter_order = int(i != 3), orders[i % 3]
+        p.grayscale, p.flip = int(i == 4), int(i % 2)
+        p.blur_sigma = [0.0, 0.1, 2.0, 0.7, 0.0, 1.3][i]
+    params[2].crop_top, params[2].crop_left, params[2].crop_h, params[2].crop_w = 30, 10, 1030, 880        # 4.6x down
+    params[1].crop_top, params[1].crop_left, params[1].crop_h, params[1].crop_w = 4, 8, 40, 50              # 5x up
+    flat = np.concatenate([im.reshape(-1) for im in imgs])
+    offs = np.cumsum([0] + [im.size for im in imgs[:-1]]).astype(np.int64)
+    hw = np.array(sizes, dtype=np.int32)
+    got = ops.image_augment(torch.from_numpy(flat).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(hw).cuda(), params, OUT)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    level = 1.0 / 255.0 / min(STD)                       # one 8-bit level after Normalize
+    for i, (im, p) in enumerate(zip(imgs, params)):
+        want = cpu_augment(im, p, OUT)
+        d = np.abs(got[i] - want)
+        frac_exact = float((d < 0.01 * level).mean())
+        print("image %d %s crop %dx%d: %.2f %% of the pixels equal, largest difference %.2f levels" % (
+            i, sizes[i], p.crop_h, p.crop_w, 100 * frac_exact, d.max() / level))
+        # the colour operations are integer-exact (tests/test_augment_cpu.py: equal to PIL); what differs is fp32 against fp64
+        # in the resampling and blur sums, i.e. a rounding flipped on a few pixels, which a following blend or the hue's 8-bit
+        # HSV round trip can stretch to a few levels on those pixels
+        assert d.max() <= 6.05 * level, (i, d.max() / level)
+        assert float((d > 1.05 * level).mean()) < 0.003 and frac_exact > 0.97, (i, frac_exact)
+    assert got.shape == (len(sizes), 3, OUT, OUT) and np.isfinite(got).all()
+
+
+def test_prefetcher_augments_decoded_images_on_the_device():
+    """a loader that stops after decode hands lists of uint8 [H,W,3] images of different sizes to DevicePrefetcher: the batch
+    comes out as the augmented, normalised [B,3,224,224] float tensor -- equal to the restatement run with the draws the
+    prefetcher made (same seed), and different from batch to batch"""
+    import random
+    from ilvlm_amd import ops
+    from ilvlm_amd.solver import DevicePrefetcher
+    rng = np.random.RandomState(11)
+    sizes = [(240, 320), (100, 90), (400, 260), (224, 224)]
+    imgs = [torch.from_numpy(rng.randint(0, 256, (h, w, 3)).astype(np.uint8)) for h, w in sizes]
+    tok = torch.zeros(4, 8, dtype=torch.int64); pad = torch.zeros(4, 8)
+    outs = list(DevicePrefetcher([(imgs, (tok, pad)), (imgs, (tok, pad))], tokenize=None, device="cuda", augment_seed=5))
+    torch.cuda.synchronize()
+    assert len(outs) == 2
+    level = 1.0 / 255.0 / min(STD)
+    for b, (img, _) in enumerate(outs):
+        assert img.shape == (4, 3, 224, 224) and img.dtype == torch.float32 and img.is_cuda
+        params = ops.mocov2_params(sizes, random.Random((5 << 32) ^ b))
+        for i in range(4):
+            want = cpu_augment(imgs[i].numpy(), params[i], 224)
+            d = np.abs(img[i].cpu().numpy() - want)
+            assert float((d > 1.05 * level).mean()) < 0.01, (b, i)
+    assert not torch.equal(outs[0][0], outs[1][0])

@@ -520,6 +520,63 @@ def test_adamw_matches_torch():
     assert torch.equal(P.cpu()[~act], p0[~act])
 
 
+def test_adamw_over_packed_weight_tiles_equals_the_chunk_kernel_and_packs():
+    """ilvlm_adamw_step_packed: the AdamW update of [out, in] GEMM weights tile by tile (64 x 64) with both fragment-order
+    images and the row-major bf16 shadow written from the tile -- parameters, moments and shadow bit for bit those of
+    ilvlm_adamw_step on the same inputs, images equal to ilvlm_gemm_pack_b of the shadow; a tile of an inactive group is left
+    untouched, images included."""
+    import ctypes as C
+    from ilvlm_amd import lib as L
+    ops = _ops()
+    lib = L.load()
+    shapes = [(192, 128), (128, 320), (64, 64)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += r * c + 64          # a gap between tensors
+    g = torch.Generator().manual_seed(5)
+    P0 = torch.randn(total, generator=g).cuda()
+    G = (torch.randn(total, generator=g) * 0.1).cuda()
+    M0 = (torch.randn(total, generator=g) * 0.01).cuda()
+    V0 = (torch.rand(total, generator=g) * 0.01).cuda()
+    h = L.AdamWHyper()
+    h.lr[0], h.weight_decay[0], h.active[0] = 1e-2, 0.1, 1
+    h.lr[1], h.weight_decay[1], h.active[1] = 3e-3, 0.0, 1
+    h.active[2] = 0
+    h.beta1, h.beta2, h.eps, h.step = 0.9, 0.98, 1e-8, 3
+    groups = [0, 1, 2]               # third weight: inactive group
+    # reference: the chunk kernel
+    P, M, V = P0.clone(), M0.clone(), V0.clone()
+    S = torch.zeros(total, dtype=torch.bfloat16, device="cuda")
+    co, cc, cg = [], [], []
+    for (r, c), o, gr in zip(shapes, offs, groups):
+        for k in range(0, r * c, 4096):
+            co.append(o + k); cc.append(min(4096, r * c - k)); cg.append(gr)
+    coff = torch.tensor(co, dtype=torch.int64).cuda(); ccnt = torch.tensor(cc, dtype=torch.int32).cuda(); cgrp = torch.tensor(cg, dtype=torch.int32).cuda()
+    L.check(lib.ilvlm_adamw_step(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), S.data_ptr(), coff.data_ptr(), ccnt.data_ptr(),
+                                 cgrp.data_ptr(), len(co), C.byref(h), None), "adamw_step")
+    # the tile kernel
+    P2, M2, V2 = P0.clone(), M0.clone(), V0.clone()
+    S2 = torch.zeros(total, dtype=torch.bfloat16, device="cuda")
+    fwd = torch.full((total,), 7.0, dtype=torch.bfloat16, device="cuda")
+    bwd = torch.full((total,), 7.0, dtype=torch.bfloat16, device="cuda")
+    tiles = [(o // 64, r, c, r0, c0, gr) for (r, c), o, gr in zip(shapes, offs, groups) for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+    table = torch.tensor(tiles, dtype=torch.int32).cuda()
+    L.check(lib.ilvlm_adamw_step_packed(P2.data_ptr(), G.data_ptr(), M2.data_ptr(), V2.data_ptr(), S2.data_ptr(), fwd.data_ptr(),
+                                        bwd.data_ptr(), table.data_ptr(), len(tiles), C.byref(h), None), "adamw_step_packed")
+    torch.cuda.synchronize()
+    assert torch.equal(P, P2) and torch.equal(M, M2) and torch.equal(V, V2) and torch.equal(S, S2)
+    assert not torch.equal(P, P0)
+    for (r, c), o, gr in zip(shapes, offs, groups):
+        w = S2[o:o + r * c].view(r, c)
+        if gr == 2:                  # inactive: nothing written
+            assert torch.equal(P2[o:o + r * c], P0[o:o + r * c]) and float((fwd[o:o + r * c] != 7).sum()) == 0
+            continue
+        assert torch.equal(fwd[o:o + r * c], ops.gemm_pack_b(w))
+        assert torch.equal(bwd[o:o + r * c], ops.gemm_pack_b(w, trans_b=True))
+        assert float((fwd[o + r * c:o + r * c + 64] != 7).sum()) == 0          # gaps untouched
+
+
 def test_small_elementwise_kernels():
     ops = _ops()
     x, y = rnd(1000, seed=1), rnd(1000, seed=2)
