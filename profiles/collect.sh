@@ -22,7 +22,7 @@ if [ "$2" = "pmc" ]; then
   # L2 hit rate of the operand streams (round 3: is the GEMM over-fetch served by the Infinity Cache or by re-reads that miss?)
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/tcc -- python3 $B --steps 2 --warmup 1 --serial-towers > $out/pmc_tcc.log 2>&1
 fi
-python3 profiles/summarize.py $out $out/summary --steps 25 > /dev/null
+python3 profiles/summarize.py $out $out/summary --steps 28 > /dev/null
 python3 profiles/timeline.py $out/stats_concurrent --skip 0.4 > $out/summary/timeline_concurrent.txt 2>&1 || true
 # keep only what is merged back: the CSV traces are large
 rm -rf $out/stats/*/*_kernel_trace.csv $out/stats_concurrent/*/*_kernel_trace.csv
