@@ -10,13 +10,14 @@ import torch
 from ilvlm_amd import ops
 
 # selectors timed side by side (GEMM_BENCH_VARIANTS=5,15 by default).  A selector may carry settings of the persistent streaming
-# kernel: "15:s1000:e2:g256" = selector 15 with a start stagger of 1000 cycles per K-tile, epilogue placement 2, 256 workgroups
+# kernel: "15:s1000:e2:g256" = selector 15 with a start stagger of 1000 cycles per K-tile, epilogue placement 2, 256 workgroups;
+# "15:t96" = 96-row tiles of the streaming kernel (t128 / t64 likewise; t0 = the per-launch cost model; default 128)
 VARIANT_SPECS = os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(",")
 
 
 def _parse(spec):
     parts = spec.split(":")
-    d = dict(v=int(parts[0]), s=-1, e=-1, g=0)
+    d = dict(v=int(parts[0]), s=-1, e=-1, g=0, t=-1)
     for q in parts[1:]:
         d[q[0]] = int(q[1:])
     return d
@@ -30,6 +31,7 @@ def select(spec):
     d = VSET[spec]
     ops.gemm_set_variant(d["v"])
     ops.gemm_set_persistent(d["g"], d["e"], d["s"])
+    ops.gemm_set_tile_rows(d["t"])
     return d["v"]
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
@@ -80,6 +82,7 @@ def run(rounds=7, only=None, epi=False, sk=True):
               "   x%.2f" % (best[VARIANTS[0]] / best[VARIANTS[-1]]), flush=True)
     ops.gemm_set_variant(15)
     ops.gemm_set_persistent(0, -1, -1)
+    ops.gemm_set_tile_rows(-1)
     print("sum of best times: " + ", ".join("v%s %.1f us" % (v, tot[v] * 1e3) for v in VARIANTS))
 
 

@@ -139,6 +139,13 @@ int ilvlm_gemm_set_variant(int variant);
  * multiplying and storing instead of doing both in lock-step (-1 = default / ILVLM_PKP_STAGGER, 0 = none; results do not
  * depend on it).  Tuning / test hook, process-wide atomics. */
 int ilvlm_gemm_set_persistent(int slots, int epi_sep, int stagger);
+/* Tile height of the streaming kernel (round 4): 128 (default), 96 or 64 rows per workgroup tile; 0 = chosen per launch by a
+ * rounds x tile-time cost model; -1 = back to the default (ILVLM_PK_TI = 8 | 6 | 4 | 0 sets it process-wide).  A launch whose
+ * 128-row tiles number fewer than the workgroup slots takes as long as ONE tile takes, and shorter tiles that still fit one
+ * round shorten it -- alone; inside the multi-stream step the empty slots are filled anyway and the shorter tiles lose
+ * (DESIGN.md section 6, round 4), hence the default.  Results do not depend on the height (same MFMA sequence per output
+ * element).  Tuning / test hook, process-wide atomic. */
+int ilvlm_gemm_set_tile_rows(int rows);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +

@@ -1299,6 +1299,17 @@ __device__ __forceinline__ void pk_dma1(pk_i32x4 rs, int voff, int soff, unsigne
         : [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff), [lds] "s"(lds), [ok] "s"(ok)
         : "scc");
 }
+// NP pieces one by one (the prologue of the tile heights whose NP is neither 4 nor 8)
+template <int NP>
+__device__ __forceinline__ void pk_dma_n(pk_i32x4 rs, int voff, int soff, int jstep, unsigned lds, int ok) {
+    if constexpr (NP == 4 || NP == 8) {
+        pk_dma<NP>(rs, voff, soff, jstep, lds, ok);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pk_dma1(rs, voff, soff + j * jstep, lds + j * 1024, ok);
+        asm volatile("" ::: "memory");
+    }
+}
 template <int OFS>
 __device__ __forceinline__ void pk_load_b1(bf16x8& b, pk_i32x4 rs, int voff, int soff, int ok) {
     asm volatile(
@@ -1325,28 +1336,38 @@ __device__ __forceinline__ void pk_load_bias(f32x4& b, pk_i32x4 rs, int voff, in
 // four MFMAs of the current one, so that a wave's own matrix pipe has work queued while a load instruction issues (a 1 KiB
 // load holds the wave's instruction stream for ~50-100 cycles; issued as one block in front of the MFMAs they cost a wave
 // ~800 cycles per K-tile without a single MFMA -- in-kernel stamps)
-template <int NP>
-__device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane,
+// TI = row tiles of 16 per wave (tile height 16 TI: 128, 96 or 64): 2 TI groups of four MFMAs per K-tile carry the 8 + NP loads
+// -- one per group from the front while they fit (TI = 8: the schedule measured in round 3), two in the leading groups of the
+// short tiles.  Issue order = wait order: the eight B loads of K-tile t + 1 first (needed at the top of the next step), then the
+// A pieces of K-tile t + 2, which the next step's counted vmcnt leaves in flight.
+template <int NP, int TI = 8>
+__device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[TI][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane,
                                               bf16x8 (&bn)[4][2], pk_i32x4 rsa, int a_voff, int a_soff, int a_jstep, unsigned lds,
                                               pk_i32x4 rsb, int b_voff, int s0, int s1, int s2, int s3, int ok_b, int ok_a) {
+    constexpr int G = 2 * TI, NL = 8 + NP;
+    static_assert(NL <= 2 * G, "at most two loads per group of four MFMAs");
     // the A fragment of group g + 1 is requested before the MFMAs of group g (the load statements between them are volatile
-    // asm: the compiler keeps their order, so it cannot hoist the reads itself).  Issue order = wait order: the eight B
-    // loads of K-tile t + 1 first (needed at the top of the next step), then the A pieces of K-tile t + 2, which the next
-    // step's counted vmcnt leaves in flight.
+    // asm: the compiler keeps their order, so it cannot hoist the reads itself)
     bf16x8 fa = p8_frag<false, 128, 64>(as, 0, 0, lane);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int ks = g >> 3, i = g & 7;
-        bf16x8 fn = fa;
-        if (g + 1 < 16) fn = p8_frag<false, 128, 64>(as, ((g + 1) & 7) * 16, ((g + 1) >> 3) * 32, lane);
-        __builtin_amdgcn_sched_barrier(0);          // keeps the read above this group's MFMAs (hipcc sinks it to reuse the register)
-        if (g < 8) {
-            const int so = (g >> 1) == 0 ? s0 : (g >> 1) == 1 ? s1 : (g >> 1) == 2 ? s2 : s3;    // column tile g >> 1, k-step g & 1
-            if (g & 1) pk_load_b1<1024>(bn[g >> 1][1], rsb, b_voff, so, ok_b);
-            else pk_load_b1<0>(bn[g >> 1][0], rsb, b_voff, so, ok_b);
-        } else if (g < 8 + NP) {
-            pk_dma1(rsa, a_voff, a_soff + (g - 8) * a_jstep, lds + (g - 8) * 1024, ok_a);
+    auto issue = [&](int idx) __attribute__((always_inline)) {
+        if (idx < 8) {
+            const int so = (idx >> 1) == 0 ? s0 : (idx >> 1) == 1 ? s1 : (idx >> 1) == 2 ? s2 : s3;    // column tile idx >> 1, k-step idx & 1
+            if (idx & 1) pk_load_b1<1024>(bn[idx >> 1][1], rsb, b_voff, so, ok_b);
+            else pk_load_b1<0>(bn[idx >> 1][0], rsb, b_voff, so, ok_b);
+        } else {
+            pk_dma1(rsa, a_voff, a_soff + (idx - 8) * a_jstep, lds + (idx - 8) * 1024, ok_a);
         }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int ks = g / TI, i = g % TI;
+        bf16x8 fn = fa;
+        if (g + 1 < G) fn = p8_frag<false, 128, 64>(as, ((g + 1) % TI) * 16, ((g + 1) / TI) * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);          // keeps the read above this group's MFMAs (hipcc sinks it to reuse the register)
+        constexpr int DBL = NL > G ? NL - G : 0;    // leading groups that carry two loads
+        const int first = g < DBL ? 2 * g : g + DBL;
+        if (first < NL) issue(first);
+        if (g < DBL) issue(first + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], fa, acc[i][j], 0, 0, 0);
         fa = fn;
@@ -1358,12 +1379,20 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[8][4], const unsigned
 // SK: compiled with the store-type split-K hand-off (a separate instantiation: its slab reduction raises the register
 // allocation from ~200 to 256 per lane, which at two waves per SIMD would leave no room for a co-resident wave of another
 // kernel -- and the step runs four streams).
-template <int WN, bool SK>
+// TI (round 4): row tiles per wave = tile height 16 TI.  At per-GPU batch 256 five of the eight store-type products of a block
+// have N = 768 / 512: 300 / 178 tiles of 128 rows for 512 workgroup slots -- ONE round however few the tiles, so the launch takes
+// what one tile takes.  96- / 64-row tiles (402 / 354 tiles: still one round) make that tile 25 / 50 % shorter; where several
+// rounds are needed anyway the shorter tile pays when it does not add one (launch_pk_auto's cost model).  Same MFMA sequence per
+// output element: bit-identical results.
+template <int WN, bool SK, int TI = 8>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
                                                                   int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NT = 64 * WN, NP = 128 * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
-    constexpr int STAGE = 128 * 64 * 2;
+    static_assert(!SK || TI == 8, "the slab split-K form is built for 128-row tiles");
+    constexpr int BMT = 16 * TI;
+    constexpr int NT = 64 * WN, NP = BMT * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
+    static_assert(NP * NT * 16 == BMT * 64 * 2 && NP >= 1, "the A stage must split into whole 1 KiB pieces per wave");
+    constexpr int STAGE = BMT * 64 * 2;
     // The forward / input-gradient chain is what the step waits for; the weight gradients that share its SIMDs (one streaming
     // wave + one weight-gradient wave is the common pairing at 221 + 151 VGPRs) are not.  Wave priority 1: 17.005 -> 16.94 ms,
     // same box, two pairs (priority 3: the same).  -DILVLM_PK_PRIO=0 for the A/B.
@@ -1387,7 +1416,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         tm = band * Hb + rr / gw;
         tn = g * G + rr % gw;
     }
-    const int m0 = tm * 128, n0 = tn * (64 * WN);
+    const int m0 = tm * BMT, n0 = tn * (64 * WN);
     // this workgroup's K-tiles [t0, t0 + nt): an equal share (the host makes split_k divide into non-empty slices)
     const int nt_all = K >> 6, per = (nt_all + split_k - 1) / split_k;
     const int t0 = zs * per, nt = min(per, nt_all - t0);
@@ -1406,9 +1435,9 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
     const int kb = (K >> 5) << 10;                                   // bytes per column tile
     int bs0 = ((n0 >> 4) + wave * 4) * kb + t0 * 2048, bs1 = bs0 + kb, bs2 = bs1 + kb, bs3 = bs2 + kb;     // + 2 KiB per K-tile
 
-    f32x4 acc[8][4];
+    f32x4 acc[TI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
     bf16x8 b0[4][2], b1[4][2];
@@ -1416,7 +1445,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
 #ifdef ILVLM_GEMM_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
     STAMP(t_start);
-#define PK_KEEP() asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][3]))
+#define PK_KEEP() asm volatile("" ::"v"(acc[0][0]), "v"(acc[TI - 1][3]))
 #else
 #define PK_KEEP()
 #endif
@@ -1446,7 +1475,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         STAMP(p2);                                                                                      \
         a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;                             \
         const int st_nn = st_cur == 0 ? 2 : st_cur - 1;       /* (st_cur + 2) % 3 */                    \
-        pk_compute_il<NP>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep,        \
+        pk_compute_il<NP, TI>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep,    \
                           lds0 + st_nn * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, more1, more2);         \
         PK_KEEP();                                                                                      \
         st_cur = st_cur == 2 ? 0 : st_cur + 1;                                                          \
@@ -1454,9 +1483,9 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         STAMP_ADD(c_wait, p0, p1); STAMP_ADD(c_bar, p1, p2); STAMP_ADD(c_comp, p2, p4);                 \
     } while (0)
         // prologue in wait order: A(0), B(0), then A(1) (which the first step's counted vmcnt leaves in flight)
-        pk_dma<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
+        pk_dma_n<NP>(rsa, a_voff, a_soff, a_jstep, lds0, 1);
         pk_load_b(b0, rsb, b_voff, bs0, bs1, bs2, bs3, 1);
-        pk_dma<NP>(rsa, a_voff, a_soff + 128, a_jstep, lds0 + STAGE, __builtin_amdgcn_readfirstlane(nt > 1 ? 1 : 0));
+        pk_dma_n<NP>(rsa, a_voff, a_soff + 128, a_jstep, lds0 + STAGE, __builtin_amdgcn_readfirstlane(nt > 1 ? 1 : 0));
         const int pairs = nt >> 1;
         for (int tp = 0; tp < pairs; ++tp) {
             PK_STEP3(b0, b1, 2 * tp);
@@ -1560,7 +1589,7 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
             }
         }
     }
-    epilogue_tile<8, 4>(ep, acc, m0, n0 + wave * 64, lane, alpha, smem_raw + wave * 8192);
+    epilogue_tile<TI, 4>(ep, acc, m0, n0 + wave * 64, lane, alpha, smem_raw + wave * 8192);
 #ifdef ILVLM_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(t_end_);
@@ -1989,18 +2018,67 @@ int launch_dma(const bf16* A, int lda, const bf16* B, int ldb, int K, int M, int
     return ILVLM_OK;
 }
 
-template <int WN>
-int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
-    constexpr int ring = 3 * 128 * 64 * 2, epi = WN * 8192;
+template <int WN, int TI>
+int launch_pk_ti(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    constexpr int ring = 3 * (16 * TI) * 64 * 2, epi = WN * 8192;
     constexpr int bytes = ring > epi ? ring : epi;
-    const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
-    if (split_k > 1)
-        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, true>), dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn,
-                           split_k, ep);
-    else
-        hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, false>), dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, 1, ep);
+    const int tm = ceil_div(M, 16 * TI), tn = ceil_div(N, 64 * WN);
+    if constexpr (TI == 8) {
+        if (split_k > 1) {
+            hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, true, 8>), dim3(tm * tn * split_k), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn,
+                               split_k, ep);
+            ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
+            return ILVLM_OK;
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, false, TI>), dim3(tm * tn), dim3(64 * WN), bytes, s, A, lda, Bp, K, tm, tn, 1, ep);
     ILVLM_LAUNCH_CHECK("gemm_bf16_pk");
     return ILVLM_OK;
+}
+
+std::atomic<int> g_pk_ti{-1};         // -1 = ILVLM_PK_TI (default 8); 8, 6, 4 force a tile height, 0 = the cost model (tests, A/B)
+
+// Tile height of a streaming launch (round 4).  A launch takes rounds x (time of one tile): the tiles of a round run side by
+// side on the 2 x CUs workgroup slots.  One tile of 16 TI rows costs, in units of a 128-row K-tile step, nt x t(TI) for its
+// K-loop -- t(TI) = (750 + 256 TI) / 2798: the MFMA work scales with the height, the eight B loads and the barrier of a step do
+// not (in-kernel stamps: 2.8 k cycles per step pair at TI = 8, of which 2 k are MFMA) -- plus E x TI / 8 for the epilogue (its
+// stores scale with the rows; E ~ 4 steps for a bf16 output, twice that for two outputs or fp32) plus a fixed 0.7 for the first
+// operands.  The height with the lowest rounds x tile cost wins; ties go to the taller tile (fewer B bytes per FLOP).
+template <int WN>
+int launch_pk(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, int split_k, const EpiArgs& ep, hipStream_t s) {
+    // Default: 128 rows everywhere.  The cost model below (ILVLM_PK_TI=0, or ilvlm_gemm_set_tile_rows(0) after a forced height)
+    // is right about launches that own the chip -- alone, cold caches, it takes 4-5 % off a block pair's forward and
+    // input-gradient launches (N = 768 products with 96 rows: -7...-11 %; the text tower's K = 512 products with 64 rows: -16 %)
+    // -- and wrong about the step: there the slots such a launch leaves empty are filled by the other tower and by the
+    // weight-gradient streams, and shorter tiles only add B-operand traffic and workgroups: 16.67-16.85 ms with 128 rows,
+    // 16.95-17.14 ms with the model's choice, 16.83 with 96 rows everywhere, 17.77 with 64 (same box,
+    // profiles/round4/step_ab_tile_rows.txt).  Kept as a tested option for single-stream use.
+    static const int ti_env = getenv("ILVLM_PK_TI") ? atoi(getenv("ILVLM_PK_TI")) : 8;
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * cus;
+    }
+    int ti = g_pk_ti.load(std::memory_order_relaxed);
+    if (ti < 0) ti = ti_env;
+    if (split_k > 1) ti = 8;
+    if (ti != 8 && ti != 6 && ti != 4) {
+        const int tn = ceil_div(N, 64 * WN), nt = K / 64;
+        const double E = (ep.e.out_dtype == ILVLM_F32 || ep.e.act == ILVLM_ACT_QUICKGELU || ep.e.act == ILVLM_ACT_GELU_ERF) ? 8.0 : 4.0;
+        double best = 1e30;
+        ti = 8;
+        for (int cand = 8; cand >= 4; cand -= 2) {
+            if (WN == 2 && cand == 6) continue;                          // (two-wave form: whole pieces per wave need TI even; kept to 8 / 4)
+            const long tiles = (long)ceil_div(M, 16 * cand) * tn;
+            const double rounds = (double)((tiles + slots - 1) / slots);
+            const double cost = rounds * (nt * (750.0 + 256.0 * cand) / 2798.0 + E * cand / 8.0 + 0.7);
+            if (cost < best - 1e-9) { best = cost; ti = cand; }
+        }
+    }
+    if (ti == 6 && WN == 4) return launch_pk_ti<WN, 6>(A, lda, Bp, K, M, N, split_k, ep, s);
+    if (ti == 4) return launch_pk_ti<WN, 4>(A, lda, Bp, K, M, N, split_k, ep, s);
+    return launch_pk_ti<WN, 8>(A, lda, Bp, K, M, N, split_k, ep, s);
 }
 
 // persistent streaming kernel: `slots` workgroups (default two per CU) walk the tiles; a grid smaller than the tile count
@@ -2306,6 +2384,16 @@ extern "C" int ilvlm_gemm_set_persistent(int slots, int epi_sep, int stagger) {
     g_pkp_slots.store(slots, std::memory_order_relaxed);
     g_pkp_epi_sep.store(epi_sep, std::memory_order_relaxed);
     g_pkp_stagger.store(stagger, std::memory_order_relaxed);
+    return ILVLM_OK;
+}
+
+// tuning / test hook of the streaming kernel: tile height in rows (128, 96, 64; 0 = the per-launch cost model; -1 = back to the
+// default, 128 rows unless ILVLM_PK_TI says otherwise)
+extern "C" int ilvlm_gemm_set_tile_rows(int rows) {
+    ILVLM_REQUIRE(rows == -1 || rows == 0 || rows == 128 || rows == 96 || rows == 64,
+                  "gemm_set_tile_rows: -1 (default), 0 (cost model), 128, 96 or 64");
+    if (rows < 0) { g_pk_ti.store(-1, std::memory_order_relaxed); return ILVLM_OK; }
+    g_pk_ti.store(rows / 16, std::memory_order_relaxed);
     return ILVLM_OK;
 }
 

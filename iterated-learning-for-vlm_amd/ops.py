@@ -333,6 +333,11 @@ def gemm_set_variant(v):
     L.check(L.load().ilvlm_gemm_set_variant(int(v)), "gemm_set_variant")
 
 
+def gemm_set_tile_rows(rows=-1):
+    """streaming kernel: tile height 128 / 96 / 64 rows, 0 = per-launch cost model, -1 = default (128)"""
+    L.check(L.load().ilvlm_gemm_set_tile_rows(int(rows)), "gemm_set_tile_rows")
+
+
 def gemm_set_persistent(slots=0, epi_sep=-1, stagger=-1):
     """persistent streaming kernel: workgroups per launch (0 = two per CU), epilogue LDS placement (-1 = default) and the start
     delay of each CU's second workgroup in cycles per K-tile (-1 = default)"""

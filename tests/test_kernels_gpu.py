@@ -700,7 +700,7 @@ def test_weight_gradient_gemm_with_ragged_reduction(K):
     assert rel(bias, a.float().sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [5, 16, 18])
+@pytest.mark.parametrize("variant", [5, 16, 18, 1696, 1664])
 @pytest.mark.parametrize("M,N,K,tb", [(19712, 2048, 512, 0), (12800, 3072, 768, 0), (12800, 768, 3072, 1), (11319, 1536, 512, 0)])
 def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, tb):
     """Chip-filling launches of the step's shapes, repeated: every launch must reproduce the first bit for bit (no atomics in
@@ -714,7 +714,11 @@ def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, 
     w = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(torch.bfloat16).cuda()
     ref = a.float() @ (w.float() if tb else w.float().t())
     wp = ops.gemm_pack_b(w, trans_b=bool(tb)) if variant >= 16 else None       # 18: the persistent streaming kernel (2 workgroups per CU walk 1.4 .. 4.8 tiles each)
+    rows = -1
+    if variant > 100:                # 1696 / 1664: the streaming kernel with 96- / 64-row tiles
+        variant, rows = 16, variant % 100
     try:
+        ops.gemm_set_tile_rows(rows)
         ops.gemm_set_variant(5)
         base = torch.empty(M, N, device="cuda", dtype=torch.float32)
         ops.gemm(a, w, base, trans_b=bool(tb))
@@ -731,6 +735,7 @@ def test_forward_gemm_is_deterministic_and_right_at_full_size(variant, M, N, K, 
                 assert torch.equal(out, first), "launch %d differs from launch 0" % it
     finally:
         ops.gemm_set_variant(15)
+        ops.gemm_set_tile_rows(-1)
 
 
 @pytest.mark.parametrize("M,N,K,tb", [(12800, 768, 3072, 0), (12800, 768, 2304, 1), (11319, 512, 2048, 0), (11319, 512, 1536, 1),
@@ -816,7 +821,8 @@ def test_pack_weights_table_equals_single_matrix_packs():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 512), (640, 400, 256), (136, 2304, 768), (8, 16, 128), (512, 256, 192),
                                    (776, 528, 320), (300, 64, 64), (129, 144, 448)])
 @pytest.mark.parametrize("tb", [0, 1])
-def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, monkeypatch):
+@pytest.mark.parametrize("rows", [128, 96, 64])
+def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, rows, monkeypatch):
     """gemm_bf16_pk_kernel (A through a two-stage LDS ring, B from the packed copy straight into registers): odd and even
     K-tile counts, ragged row tiles, column counts that are not multiples of the 128-column tile, every store epilogue --
     against an fp32 reference AND bit for bit against the direct-to-LDS kernel"""
@@ -850,11 +856,13 @@ def test_streaming_gemm_equals_direct_to_lds_kernel(M, N, K, tb, monkeypatch):
 
     try:
         ops.gemm_set_variant(16)         # the streaming kernel for every eligible shape (15 keeps short K-loops on the other kernel)
+        ops.gemm_set_tile_rows(rows)     # every tile height of the kernel (round 4: 96- and 64-row tiles beside the 128-row one)
         got = run(wp)
         ops.gemm_set_variant(5)
         base = run(None)
     finally:
         ops.gemm_set_variant(15)
+        ops.gemm_set_tile_rows(-1)
     assert rel(got[0], ref) < 2e-5
     assert rel(got[2], ref + bias + res) < 2e-5
     for i, (g, b) in enumerate(zip(got, base)):
