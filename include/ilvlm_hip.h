@@ -151,6 +151,12 @@ int ilvlm_gemm_set_tile_rows(int rows);
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +
  * 8 (l >> 4) + j], j = 0..7 -- the operand register image of v_mfma_f32_16x16x32_bf16.  N % 16 == 0, K % 32 == 0. */
 int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int ldb, void* packed, void* stream);
+/* fp8 (e4m3) B operand, row-major B8[n * ldb + k], in the fragment order of the streaming kernel's fp8 form (b_packed with
+ * compute dtype ILVLM_FP8 / ILVLM_FP8_BF8A, (0,0) layout): the 16 x 128 block (n / 16, k / 128) is 2 contiguous KiB, block index
+ * (n / 16) * (K / 128) + k / 128; lane l owns bytes [16 l, 16 l + 16) of the first KiB = B8[16 (n/16) + (l & 15)][128 (k/128) +
+ * 16 (l >> 4) + j] and the same bytes of the second KiB = ... [128 (k/128) + 64 + 16 (l >> 4) + j], j = 0..15 -- together the
+ * 32-byte operand of v_mfma_scale_f32_16x16x128_f8f6f4.  N % 16 == 0, K % 128 == 0.  Bit-identical results to the row-major call. */
+int ilvlm_gemm_pack_b8(int N, int K, const void* B8, int ldb, void* packed, void* stream);
 /* The same for every GEMM weight of a flat bf16 parameter arena in one launch (nn.Linear weights [out, in] of the residual
  * attention blocks; base_transformer.py:35-48): table = n_tiles x {arena offset / 64, rows, cols, r0, c0} int32, one entry
  * per 64 x 64 tile of a weight (rows, cols and the offset multiples of 64).  fwd (same offsets) receives the trans_b = 0
@@ -304,6 +310,11 @@ int ilvlm_fp8_quantize(const void* src, int src_dtype, void* dst, long n, const 
  * transpose [cols, rows] (input-gradient operand), both at the tensor's offset in an arena-shaped byte buffer. */
 int ilvlm_fp8_quantize_weights(const float* params, void* w8, void* w8t, const int32_t* tile_table, int n_tiles,
                                const float* scale, float* amax, void* stream);
+/* as above, plus both copies in the fragment order the streaming GEMM reads with fp8 operands (w8p: forward operand, w8tp:
+ * input-gradient operand; ilvlm_gemm_epilogue.b_packed, layout of ilvlm_gemm_pack_b8), each at the tensor's arena offset.
+ * Every matrix of the table needs rows % 128 == 0 and cols % 128 == 0. */
+int ilvlm_fp8_quantize_weights_packed(const float* params, void* w8, void* w8t, void* w8p, void* w8tp, const int32_t* tile_table,
+                                      int n_tiles, const float* scale, float* amax, void* stream);
 int ilvlm_fp8_scale_update(float* amax_cur, float* hist, float* scale, float* inv_scale, const float* fmt_max, int n_slots,
                            int hist_len, int pos, void* stream);
 
@@ -435,6 +446,9 @@ typedef struct ilvlm_block {
      * run the streaming kernel (ilvlm_gemm_epilogue.b_packed); NULL = the direct-to-LDS kernel on the row-major weights. */
     const void *in_wp, *out_wp, *fc_wp, *proj_wp;
     const void *in_wpt, *out_wpt, *fc_wpt, *proj_wpt;
+    /* the same for fp8 >= 2: fragment-order copies of *_w8 / *_w8t (ilvlm_fp8_quantize_weights_packed); NULL = direct-to-LDS */
+    const void *in_w8p, *out_w8p, *fc_w8p, *proj_w8p;
+    const void *in_w8tp, *out_w8tp, *fc_w8tp, *proj_w8tp;
 } ilvlm_block;
 long ilvlm_block_saved_bytes(const ilvlm_block* b, long rows, int B, int L);
 long ilvlm_block_scratch_bytes(const ilvlm_block* b, long rows);

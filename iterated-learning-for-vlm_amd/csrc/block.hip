@@ -121,9 +121,10 @@ int f8_quant(const ilvlm_block* b, const void* x, long n, int slot, int e5m2, vo
 
 // forward linear: y = x W^T (+ epilogue); fp8 operands when x8 is given
 int linear_fwd(const ilvlm_block* b, const void* x, const void* x8, int slot_a, const void* W, const void* W8, int slot_w,
-               void* y, long M, int N, int K, ilvlm_gemm_epilogue ep, hipStream_t s, const void* Wp = nullptr) {
+               void* y, long M, int N, int K, ilvlm_gemm_epilogue ep, hipStream_t s, const void* Wp = nullptr, const void* W8p = nullptr) {
     ep.b_packed = (!x8 && b->dtype == ILVLM_BF16) ? Wp : nullptr;      // fragment-order weights: the streaming kernel
     if (x8) {
+        ep.b_packed = W8p;
         ep.alpha_ptr = b->f8_inv + slot_a;
         ep.alpha_ptr2 = b->f8_inv + slot_w;
         return ilvlm_gemm(ILVLM_FP8, 0, 0, (int)M, N, K, x8, K, W8, K, y, N, &ep, 1, s);
@@ -182,7 +183,7 @@ int linear_bwd(const ilvlm_block* b, int dtype, const void* dy, const void* x, c
                int dx_act, const void* dx_aux, int wgrad_target, hipStream_t s, hipStream_t wg, const void* dy8 = nullptr,
                const void* W8T = nullptr, const float* inv_g = nullptr, const float* inv_w = nullptr, void* dx8 = nullptr,
                const float* dx8_scale = nullptr, float* dx8_amax = nullptr, const void* x8 = nullptr,
-               const float* inv_x = nullptr, const void* Wpt = nullptr, WgradBatch* defer = nullptr) {
+               const float* inv_x = nullptr, const void* Wpt = nullptr, WgradBatch* defer = nullptr, const void* W8Tp = nullptr) {
     const bool fuse_b = gb && gW && dtype == ILVLM_BF16 && N % 8 == 0 && N >= 8;
     const bool f8w = dy8 && x8;
     const int wdt = f8w ? ILVLM_FP8_BF8A : dtype;
@@ -238,6 +239,7 @@ int linear_bwd(const ilvlm_block* b, int dtype, const void* dy, const void* x, c
     if (dy8) {      // dx[m,k] = sum_n dy8[m,n] W8T[k,n]
         ep.alpha_ptr = inv_g;
         ep.alpha_ptr2 = inv_w;
+        ep.b_packed = W8Tp;
         return ilvlm_gemm(ILVLM_FP8_BF8A, 0, 0, (int)M, K, N, dy8, N, W8T, N, dx, K, &ep, 1, s);
     }
     ep.b_packed = dtype == ILVLM_BF16 ? Wpt : nullptr;     // fragment-order image of W for dx = dy W
@@ -284,7 +286,7 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.alpha = 1.0f;
     ep.out_dtype = T;
     ep.bias = b->in_b;
-    TRY(linear_fwd(b, h1, f8on ? h1_8 : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s, b->in_wp));
+    TRY(linear_fwd(b, h1, f8on ? h1_8 : nullptr, F8_H1, b->in_w, b->in_w8, F8_IN_W, qkv, rows, 3 * E, E, ep, s, b->in_wp, b->in_w8p));
     if (f8on) {                  // the attention kernel emits the e4m3 copy of its output itself
         TRY(ilvlm_attention_fwd_q8(qkv, att, lse, T, B, L, Lcap, b->H, b->causal, seq_offs, att8, sc + F8_ATT, am + F8_ATT, stream));
         x8 = att8;
@@ -298,7 +300,7 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->out_b;
     ep.residual = x_in;
-    TRY(linear_fwd(b, att, x8, F8_ATT, b->out_w, b->out_w8, F8_OUT_W, x_mid, rows, E, E, ep, s, b->out_wp));
+    TRY(linear_fwd(b, att, x8, F8_ATT, b->out_w, b->out_w8, F8_OUT_W, x_mid, rows, E, E, ep, s, b->out_wp, b->out_w8p));
     // x_out = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
     TRY(ilvlm_layernorm_fwd_q8(x_mid, ILVLM_F32, b->ln2_w, b->ln2_b, h2, T, mean2, rstd2, rows, E, 1e-5f, 0, 0, f8on ? h2_8 : nullptr,
                                f8on ? sc + F8_H2 : nullptr, f8obs ? am + F8_H2 : nullptr, stream));
@@ -314,13 +316,13 @@ extern "C" int ilvlm_block_fwd(const ilvlm_block* b, const float* x_in, float* x
         ep.out8_amax = am + F8_G;
         ep.out8_fmt = 0;
     }
-    TRY(linear_fwd(b, h2, f8on ? h2_8 : nullptr, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s, b->fc_wp));
+    TRY(linear_fwd(b, h2, f8on ? h2_8 : nullptr, F8_H2, b->fc_w, b->fc_w8, F8_FC_W, g, rows, 4 * E, E, ep, s, b->fc_wp, b->fc_w8p));
     ep = {};
     ep.alpha = 1.0f;
     ep.out_dtype = ILVLM_F32;
     ep.bias = b->proj_b;
     ep.residual = x_mid;
-    return linear_fwd(b, g, f8on ? g8 : nullptr, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s, b->proj_wp);
+    return linear_fwd(b, g, f8on ? g8 : nullptr, F8_G, b->proj_w, b->proj_w8, F8_PROJ_W, x_out, rows, E, 4 * E, ep, s, b->proj_wp, b->proj_w8p);
 }
 
 extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const void* saved, const float* dx_f32,
@@ -388,9 +390,9 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(b, T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
                    g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,
-                   f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G, b->proj_wpt, wb));
+                   f8obs ? am + F8_DU : nullptr, g8a, inv + F8_G, b->proj_wpt, wb, b->proj_w8tp));
     TRY(linear_bwd(b, T, du, h2, b->fc_w, b->g_fc_w, b->g_fc_b, dh2, rows, 4 * E, E, 0, nullptr, wgrad_target, s, wg,
-                   f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2, b->fc_wpt, wb));
+                   f8on ? du8 : nullptr, b->fc_w8t, inv + F8_DU, inv + F8_FC_W, nullptr, nullptr, nullptr, h2_8, inv + F8_H2, b->fc_wpt, wb, b->fc_w8tp));
     ILVLM_REQUIRE(b->g_ln1_w && b->g_ln1_b && b->g_ln2_w && b->g_ln2_b, "block_bwd: frozen LayerNorm parameters are not supported");
     if (f8wg) dmid_lp = nullptr;
     TRY(ilvlm_layernorm_bwd_q8(dh2, T, x_mid, ILVLM_F32, mean2, rstd2, b->ln2_w, dx_f32, dmid, dmid_lp, T, 0, nullptr, b->g_ln2_w,
@@ -400,7 +402,7 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     dy = lp ? (const void*)dmid_lp : (const void*)dmid;
     TRY(linear_bwd(b, T, dy, att, b->out_w, b->g_out_w, b->g_out_b, da, rows, E, E, 0, nullptr, wgrad_target, s, wg,
                    f8on ? dmid8 : nullptr, b->out_w8t, inv + F8_DMID, inv + F8_OUT_W, nullptr, nullptr, nullptr, att8, inv + F8_ATT,
-                   b->out_wpt, wb));
+                   b->out_wpt, wb, b->out_w8tp));
     if (f8on) {                  // the attention backward kernels emit the e5m2 copy of dqkv themselves (all sequence lengths)
         if (f8wg) dqkv = nullptr;
         TRY(ilvlm_attention_bwd_q8(da, qkv, att, lse, dqkv, T, B, L, Lcap, b->H, b->causal, seq_offs, dqkv8, sc + F8_DQKV,
@@ -431,15 +433,15 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
             wb->rows = rows;
             TRY(flush_wgrad(wb, s, wg));
             TRY(linear_bwd(b, T, dqkv, h1, b->in_w, nullptr, nullptr, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
-                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt, nullptr, b->in_w8tp));
         } else {
             TRY(flush_wgrad(wb, s, wg));
             TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
-                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+                           inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt, nullptr, b->in_w8tp));
         }
     } else {
         TRY(linear_bwd(b, T, dqkv, h1, b->in_w, b->g_in_w, b->g_in_b, dh1, rows, 3 * E, E, 0, nullptr, wgrad_target, s, wg, g8, b->in_w8t,
-                       inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt));
+                       inv + F8_DQKV, inv + F8_IN_W, nullptr, nullptr, nullptr, h1_8, inv + F8_H1, b->in_wpt, nullptr, b->in_w8tp));
     }
     return ilvlm_layernorm_bwd_q8(dh1, T, x_in, ILVLM_F32, mean1, rstd1, b->ln1_w, dmid, din_f32,
                                   lp ? din_lp : nullptr, T, 0,

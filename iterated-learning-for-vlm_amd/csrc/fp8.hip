@@ -39,8 +39,12 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const T* __restrict__ sr
 
 // weights: 64 x 64 tiles of the fp32 master arena -> e4m3 in the same [rows, cols] layout (forward operand) and
 // transposed [cols, rows] (input-gradient operand: dX = dY W needs W with the reduction index contiguous)
+// W8P / W8TP (optional): the same bytes in the fragment order of the streaming kernel's fp8 form (gemm.hip, pack_b8_kernel):
+// block (row / 16, k / 128) of 2 KiB, 16-byte chunk number 64 * ((k / 64) & 1) + (row & 15) + 16 * ((k / 16) & 3) -- a thread's 16
+// bytes are one chunk, so the packed copies cost one more store each.  The packed image of a matrix starts at its arena offset.
 __global__ __launch_bounds__(256) void fp8_weight_kernel(const float* __restrict__ P, unsigned char* __restrict__ W8,
-                                                         unsigned char* __restrict__ W8T, const int* __restrict__ table,
+                                                         unsigned char* __restrict__ W8T, unsigned char* __restrict__ W8P,
+                                                         unsigned char* __restrict__ W8TP, const int* __restrict__ table,
                                                          const float* __restrict__ scale, float* __restrict__ amax) {
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) unsigned char tile[64][64 + 16];
@@ -60,13 +64,24 @@ __global__ __launch_bounds__(256) void fp8_weight_kernel(const float* __restrict
         w[k] = pack4<0>(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
     }
     *(uint4*)(W8 + off + (long)(r0 + r) * cols + c0 + cq) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (W8P) {
+        const int n = r0 + r, k = c0 + cq;
+        const long chunk = ((long)(n >> 4) * (cols >> 7) + (k >> 7)) * 128 + ((k >> 6) & 1) * 64 + (n & 15) + ((k >> 4) & 3) * 16;
+        *(uint4*)(W8P + off + chunk * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[cq + 4 * k + j][r] = (unsigned char)(w[k] >> (8 * j));
     __syncthreads();
     // transposed tile: row c (a column of the weight), 64 consecutive original rows
-    *(uint4*)(W8T + off + (long)(c0 + r) * rows + r0 + cq) = *(const uint4*)&tile[r][cq];
+    const uint4 tv = *(const uint4*)&tile[r][cq];
+    *(uint4*)(W8T + off + (long)(c0 + r) * rows + r0 + cq) = tv;
+    if (W8TP) {
+        const int n = c0 + r, k = r0 + cq;
+        const long chunk = ((long)(n >> 4) * (rows >> 7) + (k >> 7)) * 128 + ((k >> 6) & 1) * 64 + (n & 15) + ((k >> 4) & 3) * 16;
+        *(uint4*)(W8TP + off + chunk * 16) = tv;
+    }
     amax_commit(m, amax + slot, red);
 }
 
@@ -118,8 +133,20 @@ extern "C" int ilvlm_fp8_quantize_weights(const float* params, void* w8, void* w
                                           const float* scale, float* amax, void* stream) {
     ILVLM_REQUIRE(params && w8 && w8t && tile_table && scale && amax && n_tiles > 0, "fp8_quantize_weights: bad args");
     hipLaunchKernelGGL(fp8_weight_kernel, dim3(n_tiles), dim3(256), 0, S_, params, (unsigned char*)w8, (unsigned char*)w8t,
-                       tile_table, scale, amax);
+                       (unsigned char*)nullptr, (unsigned char*)nullptr, tile_table, scale, amax);
     ILVLM_LAUNCH_CHECK("fp8_quantize_weights");
+    return ILVLM_OK;
+}
+
+// as above, plus the fragment-order copies the streaming fp8 GEMM reads (ilvlm_gemm's b_packed with fp8 compute).  Every matrix
+// of the table needs rows %% 128 == 0 and cols %% 128 == 0 (the caller's check: the table holds 64 x 64 tiles only).
+extern "C" int ilvlm_fp8_quantize_weights_packed(const float* params, void* w8, void* w8t, void* w8p, void* w8tp,
+                                                 const int32_t* tile_table, int n_tiles, const float* scale, float* amax, void* stream) {
+    ILVLM_REQUIRE(params && w8 && w8t && w8p && w8tp && tile_table && scale && amax && n_tiles > 0, "fp8_quantize_weights_packed: bad args");
+    ILVLM_REQUIRE(((uintptr_t)w8p % 16) == 0 && ((uintptr_t)w8tp % 16) == 0, "fp8_quantize_weights_packed: alignment");
+    hipLaunchKernelGGL(fp8_weight_kernel, dim3(n_tiles), dim3(256), 0, S_, params, (unsigned char*)w8, (unsigned char*)w8t,
+                       (unsigned char*)w8p, (unsigned char*)w8tp, tile_table, scale, amax);
+    ILVLM_LAUNCH_CHECK("fp8_quantize_weights_packed");
     return ILVLM_OK;
 }
 

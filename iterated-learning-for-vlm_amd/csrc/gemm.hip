@@ -43,6 +43,13 @@ __device__ __forceinline__ void out8_store(const ilvlm_gemm_epilogue& e, long of
         for (int i = 0; i < nvalid; ++i) p[i] = (unsigned char)(w >> (8 * i));
 }
 
+__device__ __forceinline__ f32x4 fma4(f32x4 v, float alpha, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(v[i], alpha, b[i]);
+    return r;
+}
+
 template <class AuxT>
 __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 v, float alpha, float* amax8 = nullptr) {
     if (m >= a.M || n >= a.N) return;
@@ -50,15 +57,25 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
     long orow = map_row(m, e.out_group, e.out_skip);
     long off = orow * (long)a.ldc + n;
     const bool full = a.vec_ok && (n + 4 <= a.N);
-    v *= alpha;
     if (e.accumulate) {
+        v *= alpha;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (n + i < a.N) atomicAdd(a.Cf + off + i, v[i]);
         return;
     }
+    // alpha * acc + bias with ONE rounding (fma4), as the whole-tile epilogues compute it: a result must not depend on whether
+    // its tile was whole, i.e. on the tile shape of the kernel that produced it
+    f32x4 b = {0, 0, 0, 0};
+    if (e.bias) {
+        if (full) b = *(const f32x4*)(e.bias + n);
+        else
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < a.N) b[i] = e.bias[n + i];
+    }
+    v = fma4(v, alpha, b);
     if (full) {
-        if (e.bias) v += *(const f32x4*)(e.bias + n);
         if (e.rowbias) v += *(const f32x4*)(e.rowbias + (long)(e.out_skip + m % e.out_group) * a.N + n);
         if (e.act) {
             AuxT* aux = (AuxT*)e.aux + off;
@@ -85,7 +102,6 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& a, int m, int n, f32x4 
     for (int i = 0; i < 4; ++i) {
         if (n + i >= a.N) break;
         float x = v[i];
-        if (e.bias) x += e.bias[n + i];
         if (e.rowbias) x += e.rowbias[(long)(e.out_skip + m % e.out_group) * a.N + n + i];
         if (e.act) {
             AuxT* aux = (AuxT*)e.aux + off + i;
@@ -618,7 +634,7 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         f32x4 v = *(const f32x4*)(wlds + row * 256 + (((2 * c8 + q) ^ (row & 15)) << 4));
-                        v = v * alpha + (q == 0 ? bias : bias_hi);
+                        v = fma4(v, alpha, q == 0 ? bias : bias_hi);
                         if constexpr (FWD_ACT) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -657,7 +673,7 @@ __device__ __forceinline__ void epilogue_pass(const EpiArgs& ep, f32x4 (&acc)[TI
                 for (int k = 0; k < 4; ++k) {
                     const int row = h * 16 + 4 * k + g;
                     f32x4 v = *(const f32x4*)(wlds + row * 256 + ((c ^ (row & 15)) << 4));
-                    v = v * alpha + bias;
+                    v = fma4(v, alpha, bias);
                     if constexpr (MODE == EPI_QGELU || MODE == EPI_GELU) {
                         store4<bf16>((bf16*)e.aux + off[k], v);
 #pragma unroll
@@ -1374,6 +1390,57 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[TI][4], const unsigne
     }
 }
 
+// fp8 operands on the streaming structure (round 4).  Two fp8 elements are addressed as one bf16 element (the host passes
+// K / 2 and lda / 2), so the A ring, the DMA and the B loads are byte for byte those of the bf16 kernel with a K-tile of 128
+// fp8 values: a lane's two 16-byte A reads of a row tile (the bf16 kernel's two k-steps) concatenate into the 32-byte operand of
+// ONE v_mfma_scale_f32_16x16x128_f8f6f4 (all block scales 2^0), and the packed B copy (ilvlm_gemm_pack_b8) stores a lane's two
+// 16-byte halves of a column tile 1 KiB apart, so b[j][0] / b[j][1] are that operand's halves as well -- both operands split
+// their k bytes the same way, the products pair up.  Per K-tile and wave: 32 scaled MFMAs (1024 cycles, as the bf16 kernel's
+// 64) beside the same 12 loads -- the direct-to-LDS fp8 kernel issues 8 loads per 16 scaled MFMAs, twice as many per MFMA cycle.
+// A_E5M2: the A operand holds e5m2 (gradients).  8 groups of four MFMAs; the 12 loads ride two per group in the first four.
+template <int NP, bool A_E5M2>
+__device__ __forceinline__ void pk_compute_il8(f32x4 (&acc)[8][4], const unsigned char* as, const bf16x8 (&b)[4][2], int lane,
+                                               bf16x8 (&bn)[4][2], pk_i32x4 rsa, int a_voff, int a_soff, int a_jstep, unsigned lds,
+                                               pk_i32x4 rsb, int b_voff, int s0, int s1, int s2, int s3, int ok_b, int ok_a) {
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    union F8 { struct { bf16x8 lo, hi; } h; v8i v; };
+    constexpr int G = 8, NL = 8 + NP;
+    static_assert(NL <= 2 * G, "at most two loads per group");
+    auto issue = [&](int idx) __attribute__((always_inline)) {
+        if (idx < 8) {
+            const int so = (idx >> 1) == 0 ? s0 : (idx >> 1) == 1 ? s1 : (idx >> 1) == 2 ? s2 : s3;
+            if (idx & 1) pk_load_b1<1024>(bn[idx >> 1][1], rsb, b_voff, so, ok_b);
+            else pk_load_b1<0>(bn[idx >> 1][0], rsb, b_voff, so, ok_b);
+        } else {
+            pk_dma1(rsa, a_voff, a_soff + (idx - 8) * a_jstep, lds + (idx - 8) * 1024, ok_a);
+        }
+    };
+    F8 fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { fb[j].h.lo = b[j][0]; fb[j].h.hi = b[j][1]; }
+    F8 fa;
+    fa.h.lo = p8_frag<false, 128, 64>(as, 0, 0, lane);
+    fa.h.hi = p8_frag<false, 128, 64>(as, 0, 32, lane);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        F8 fn = fa;
+        if (g + 1 < G) {
+            fn.h.lo = p8_frag<false, 128, 64>(as, (g + 1) * 16, 0, lane);
+            fn.h.hi = p8_frag<false, 128, 64>(as, (g + 1) * 16, 32, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int DBL = NL > G ? NL - G : 0;
+        const int first = g < DBL ? 2 * g : g + DBL;
+        if (first < NL) issue(first);
+        if (g < DBL) issue(first + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)      // cbsz / blgp: 0 = e4m3, 1 = e5m2 (first operand = B = weights, second = A); scale bytes 0x7f = 2^0
+            acc[g][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j].v, fa.v, acc[g][j], 0, A_E5M2 ? 1 : 0, 0, 0x7f7f7f7f, 0,
+                                                                         0x7f7f7f7f);
+        fa = fn;
+    }
+}
+
 #endif
 
 // SK: compiled with the store-type split-K hand-off (a separate instantiation: its slab reduction raises the register
@@ -1384,11 +1451,12 @@ __device__ __forceinline__ void pk_compute_il(f32x4 (&acc)[TI][4], const unsigne
 // what one tile takes.  96- / 64-row tiles (402 / 354 tiles: still one round) make that tile 25 / 50 % shorter; where several
 // rounds are needed anyway the shorter tile pays when it does not add one (launch_pk_auto's cost model).  Same MFMA sequence per
 // output element: bit-identical results.
-template <int WN, bool SK, int TI = 8>
+template <int WN, bool SK, int TI = 8, int F8 = 0>       // F8: 0 bf16 operands, 1 e4m3 x e4m3, 2 e5m2 (A) x e4m3 (pk_compute_il8)
 __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ Bp,
                                                                   int K, int tiles_m, int tiles_n, int split_k, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!SK || TI == 8, "the slab split-K form is built for 128-row tiles");
+    static_assert(F8 == 0 || (TI == 8 && !SK), "fp8 operands: 128-row tiles, no K split");
     constexpr int BMT = 16 * TI;
     constexpr int NT = 64 * WN, NP = BMT * 64 * 2 / (NT * 16);      // DMA pieces per wave and K-tile
     static_assert(NP * NT * 16 == BMT * 64 * 2 && NP >= 1, "the A stage must split into whole 1 KiB pieces per wave");
@@ -1475,8 +1543,12 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_bf16_pk_kernel(const bf16* __
         STAMP(p2);                                                                                      \
         a_soff += 128; bs0 += 2048; bs1 += 2048; bs2 += 2048; bs3 += 2048;                             \
         const int st_nn = st_cur == 0 ? 2 : st_cur - 1;       /* (st_cur + 2) % 3 */                    \
-        pk_compute_il<NP, TI>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep,    \
-                          lds0 + st_nn * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, more1, more2);         \
+        if constexpr (F8 == 0)                                                                          \
+            pk_compute_il<NP, TI>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep,    \
+                                  lds0 + st_nn * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, more1, more2);  \
+        else                                                                                            \
+            pk_compute_il8<NP, F8 == 2>(acc, smem_raw + st_cur * STAGE, BCUR, lane, BNXT, rsa, a_voff, a_soff + 128, a_jstep, \
+                                        lds0 + st_nn * STAGE, rsb, b_voff, bs0, bs1, bs2, bs3, more1, more2); \
         PK_KEEP();                                                                                      \
         st_cur = st_cur == 2 ? 0 : st_cur + 1;                                                          \
         STAMP(p4);                                                                                      \
@@ -2036,6 +2108,18 @@ int launch_pk_ti(const bf16* A, int lda, const bf16* Bp, int K, int M, int N, in
     return ILVLM_OK;
 }
 
+// fp8 operands (K = number of fp8 values per row; the kernel is told K / 2 "bf16 elements")
+template <int WN, int F8>
+int launch_pk8(const void* A8, int lda, const void* Bp8, int K, int M, int N, const EpiArgs& ep, hipStream_t s) {
+    constexpr int ring = 3 * 128 * 64 * 2, epi = WN * 8192;
+    constexpr int bytes = ring > epi ? ring : epi;
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 64 * WN);
+    hipLaunchKernelGGL((gemm_bf16_pk_kernel<WN, false, 8, F8>), dim3(tm * tn), dim3(64 * WN), bytes, s, (const bf16*)A8, lda / 2,
+                       (const bf16*)Bp8, K / 2, tm, tn, 1, ep);
+    ILVLM_LAUNCH_CHECK("gemm_fp8_pk");
+    return ILVLM_OK;
+}
+
 std::atomic<int> g_pk_ti{-1};         // -1 = ILVLM_PK_TI (default 8); 8, 6, 4 force a tile height, 0 = the cost model (tests, A/B)
 
 // Tile height of a streaming launch (round 4).  A launch takes rounds x (time of one tile): the tiles of a round run side by
@@ -2238,6 +2322,17 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
             slab_setup(128);
             return launch_dma<true, true, false, 128, 128, 2, 2, 1, 64, 3>((const bf16*)A, lda, (const bf16*)B, ldb, K, M, N, split_k, ep, s);
         }
+        // streaming form: the caller offers the e4m3 B operand in fragment order (ilvlm_gemm_pack_b8 / the weight quantiser)
+        static const int pk8_env = getenv("ILVLM_FP8_PK") ? atoi(getenv("ILVLM_FP8_PK")) : 1;
+        const int variant8 = g_gemm_variant.load(std::memory_order_relaxed);
+        if (pk8_env && variant8 >= 15 && epi->b_packed && N % 16 == 0 && (long)N * K < (1L << 31) && ((long)(M - 1) * lda + K) < (1L << 31) &&
+            aligned(epi->b_packed, 16)) {
+            ep.tile_group = 0;
+            const bool wide4 = N % 256 == 0;
+            if (compute_dtype == ILVLM_FP8)
+                return wide4 ? launch_pk8<4, 1>(A, lda, epi->b_packed, K, M, N, ep, s) : launch_pk8<2, 1>(A, lda, epi->b_packed, K, M, N, ep, s);
+            return wide4 ? launch_pk8<4, 2>(A, lda, epi->b_packed, K, M, N, ep, s) : launch_pk8<2, 2>(A, lda, epi->b_packed, K, M, N, ep, s);
+        }
         if (compute_dtype == ILVLM_FP8)
             return launch_dma<false, false, true, 128, 128, 2, 2, 1, 64, 1>((const bf16*)A, lda / 2, (const bf16*)B, ldb / 2, K / 2, M, N,
                                                                            1, ep, s);
@@ -2404,6 +2499,29 @@ extern "C" int ilvlm_gemm_pack_b(int trans_b, int N, int K, const void* B, int l
     hipLaunchKernelGGL(pack_b_kernel, dim3((int)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)B, ldb,
                        trans_b, N, K, (bf16*)packed);
     ILVLM_LAUNCH_CHECK("gemm_pack_b");
+    return ILVLM_OK;
+}
+
+// packed copy of an fp8 B operand (ilvlm_gemm_pack_b8): one thread per 16-byte chunk.  Block (n / 16, k / 128) = 16 rows x 128
+// bytes = 2 KiB; lane l = (n & 15) + 16 g owns bytes [16 g, 16 g + 16) and [64 + 16 g, ...) of its row: the first halves of
+// the 64 lanes form the first KiB of the block, the second halves the second
+__global__ __launch_bounds__(256) void pack_b8_kernel(const unsigned char* __restrict__ B, int ldb, int N, int K, unsigned char* __restrict__ out) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (long)N * K / 16) return;
+    const int l = (int)(c & 63), half = (int)((c >> 6) & 1);
+    const long blk = c >> 7;
+    const int kblocks = K >> 7;
+    const int n = (int)(blk / kblocks) * 16 + (l & 15), k0 = (int)(blk % kblocks) * 128 + 64 * half + 16 * (l >> 4);
+    *(uint4*)(out + c * 16) = *(const uint4*)(B + (long)n * ldb + k0);
+}
+
+extern "C" int ilvlm_gemm_pack_b8(int N, int K, const void* B8, int ldb, void* packed, void* stream) {
+    ILVLM_REQUIRE(B8 && packed && N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "gemm_pack_b8: N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+    ILVLM_REQUIRE(ldb >= K && ldb % 16 == 0 && aligned(B8, 16) && aligned(packed, 16), "gemm_pack_b8: alignment / ldb");
+    const long chunks = (long)N * K / 16;
+    hipLaunchKernelGGL(pack_b8_kernel, dim3((int)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)B8, ldb, N, K,
+                       (unsigned char*)packed);
+    ILVLM_LAUNCH_CHECK("gemm_pack_b8");
     return ILVLM_OK;
 }
 

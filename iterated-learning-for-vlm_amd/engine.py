@@ -184,12 +184,21 @@ class Fp8State:
         self.table = torch.tensor(table, dtype=torch.int32).to(dev)
         self.W8 = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
         self.W8T = torch.zeros(arena.total, dtype=torch.uint8, device=dev)
+        # fragment-order copies for the streaming kernel (ILVLM_FP8_PACK=0: the direct-to-LDS kernel on W8 / W8T)
+        self.pack = os.environ.get("ILVLM_FP8_PACK", "1") != "0" and all(r % 128 == 0 and c % 128 == 0 for _, r, c, _, _, _ in table)
+        self.W8P = torch.zeros(arena.total, dtype=torch.uint8, device=dev) if self.pack else None
+        self.W8TP = torch.zeros(arena.total, dtype=torch.uint8, device=dev) if self.pack else None
         self.steps = 0            # training forwards begun = scale updates done; 0 = nothing observed yet
         self.bwd_seen = 0         # backward passes observed (their gradient amaxes are what the e5m2 scales come from)
         self.w_observed = False   # weight amaxes recorded once
         self.active = False       # False: observe only (bf16 GEMMs); True: fp8 GEMMs
 
     def _quantize_weights(self, st):
+        if self.pack:
+            ops.L.check(ops.L.load().ilvlm_fp8_quantize_weights_packed(
+                self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(), self.W8P.data_ptr(), self.W8TP.data_ptr(),
+                self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(), self.amax.data_ptr(), st), "fp8_quantize_weights_packed")
+            return
         ops.L.check(ops.L.load().ilvlm_fp8_quantize_weights(self.arena.P.data_ptr(), self.W8.data_ptr(), self.W8T.data_ptr(),
                                                             self.table.data_ptr(), self.table.shape[0], self.scale.data_ptr(),
                                                             self.amax.data_ptr(), st), "fp8_quantize_weights")
@@ -231,6 +240,15 @@ class Fp8State:
         o = self.arena.offsets[name]
         r, c = self.arena.views[name].shape
         return (self.W8T[o:o + r * c].view(c, r) if transposed else self.W8[o:o + r * c].view(r, c))
+
+    def w8p(self, pre, k, transposed=False):
+        """fragment-order copy of w8(...) (flat), None without the packed copies"""
+        if not self.pack:
+            return None
+        name = pre + self.WNAME[k]
+        o = self.arena.offsets[name]
+        r, c = self.arena.views[name].shape
+        return (self.W8TP if transposed else self.W8P)[o:o + r * c]
 
     def quant(self, x, key, e5m2=False):
         """fp8 copy of x for slot `key` (None while only observing); always records the amax"""
@@ -454,6 +472,9 @@ class Engine:
                     for k in f8.WEIGHT:
                         setattr(d, k + "8", f8.w8(pre, k).data_ptr())
                         setattr(d, k + "8t", f8.w8(pre, k, transposed=True).data_ptr())
+                        if f8.pack:
+                            setattr(d, k + "8p", f8.w8p(pre, k).data_ptr())
+                            setattr(d, k + "8tp", f8.w8p(pre, k, transposed=True).data_ptr())
                     d.f8_scale = f8.scale[base:].data_ptr()
                     d.f8_inv = f8.inv[base:].data_ptr()
                     d.f8_amax = f8.amax[base:].data_ptr()
@@ -513,7 +534,7 @@ class Engine:
         dx = _empty((M, K), self.T, dy)
         if dy8 is not None:
             ops.gemm_fp8(dy8, self.fp8.w8(pre, kw_, transposed=True), dx, self.fp8.s(pre + kg)[1], self.fp8.s(pre + kw_)[1],
-                         a_e5m2=True, aux=dx_aux, act=dx_act)
+                         a_e5m2=True, aux=dx_aux, act=dx_act, b_packed=self.fp8.w8p(pre, kw_, transposed=True))
         else:
             ops.gemm(dy, self._mat(wname), dx, trans_b=True, aux=dx_aux, act=dx_act, b_packed=self._packed(wname, backward=True))
         return dx
@@ -536,7 +557,7 @@ class Engine:
             """x [M,K] (T) . W^T: fp8 operands when the fp8 mode is active, else the compute-dtype GEMM"""
             x8 = f8.quant(x, pre + key_a) if f8 is not None else None
             if x8 is not None:
-                ops.gemm_fp8(x8, f8.w8(pre, key_w), out, f8.s(pre + key_a)[1], f8.s(pre + key_w)[1], **kw)
+                ops.gemm_fp8(x8, f8.w8(pre, key_w), out, f8.s(pre + key_a)[1], f8.s(pre + key_w)[1], b_packed=f8.w8p(pre, key_w), **kw)
             else:
                 ops.gemm(x, self._mat(pre + wname), out, b_packed=self._packed(pre + wname), **kw)
             return x8

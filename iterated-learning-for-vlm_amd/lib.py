@@ -33,7 +33,8 @@ class Block(C.Structure):
                 [(n, vp) for n in ("in_w8", "out_w8", "fc_w8", "proj_w8", "in_w8t", "out_w8t", "fc_w8t", "proj_w8t", "f8_scale",
                                    "f8_inv", "f8_amax")] + [("fp8", i32)] +
                 [("splitk_ws", vp), ("splitk_ws_bytes", i64), ("splitk_cnt", vp), ("splitk_cnt_len", i32)] +
-                [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")])
+                [(n, vp) for n in ("in_wp", "out_wp", "fc_wp", "proj_wp", "in_wpt", "out_wpt", "fc_wpt", "proj_wpt")] +
+                [(n, vp) for n in ("in_w8p", "out_w8p", "fc_w8p", "proj_w8p", "in_w8tp", "out_w8tp", "fc_w8tp", "proj_w8tp")])
 
 
 class AugmentParams(C.Structure):
@@ -106,6 +107,8 @@ SIGNATURES = {
     "ilvlm_colsum": [vp, i32, vp, i64, i32, i32, vp],
     "ilvlm_fp8_quantize": [vp, i32, vp, i64, vp, vp, i32, vp],
     "ilvlm_fp8_quantize_weights": [vp, vp, vp, vp, i32, vp, vp, vp],
+    "ilvlm_fp8_quantize_weights_packed": [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp],
+    "ilvlm_gemm_pack_b8": [i32, i32, vp, i32, vp, vp],
     "ilvlm_fp8_scale_update": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "ilvlm_image_u8_normalize": [vp, i32, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
     "ilvlm_image_augment_scratch_floats": [i32, i32, i32],

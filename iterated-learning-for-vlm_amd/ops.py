@@ -192,9 +192,10 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, rowbias=None, re
     return out
 
 
-def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual=None, aux=None, act=0):
+def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual=None, aux=None, act=0, b_packed=None):
     """out[m,n] = epilogue(inv_a * inv_b * sum_k a8[m,k] b8[n,k]); a8 [M,K], b8 [N,K] uint8 holding OCP fp8 (e4m3; a8
-    e5m2 with a_e5m2), scale_a / scale_b: 1-element fp32 device tensors with the de-quantisation factors."""
+    e5m2 with a_e5m2), scale_a / scale_b: 1-element fp32 device tensors with the de-quantisation factors.
+    b_packed: b8 in fragment order (gemm_pack_b8 / the packed weight quantiser): the streaming kernel, same results."""
     _chk(a8, "gemm_fp8.a", torch.uint8); _chk(b8, "gemm_fp8.b", torch.uint8); _chk(out, "gemm_fp8.out")
     m, k = a8.shape
     n = b8.shape[0]
@@ -208,6 +209,11 @@ def gemm_fp8(a8, b8, out, scale_a, scale_b, *, a_e5m2=False, bias=None, residual
         _chk(aux, "gemm_fp8.aux", torch.bfloat16, (m, n))
     epi = GemmEpilogue(_p(bias), None, _p(residual), _p(aux), scale_a.data_ptr(), 1.0, int(act), dt(out), 0, 0, 0, None,
                        None, None, None, 0, scale_b.data_ptr())
+    if b_packed is not None:
+        _chk(b_packed, "gemm_fp8.b_packed", torch.uint8)
+        if b_packed.numel() != n * k:
+            raise RuntimeError("gemm_fp8: b_packed must hold n * k = %d bytes, got %d" % (n * k, b_packed.numel()))
+        epi.b_packed = b_packed.data_ptr()
     prof = _gemm_profiler
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -270,6 +276,17 @@ def gemm_pack_b(b, trans_b=False, out=None):
         out = torch.empty(n * k, dtype=torch.bfloat16, device=b.device)
     _chk(out, "gemm_pack_b.out", torch.bfloat16, (n * k,))
     L.check(L.load().ilvlm_gemm_pack_b(int(trans_b), n, k, b.data_ptr(), b.stride(0), out.data_ptr(), _stream()), "gemm_pack_b")
+    return out
+
+
+def gemm_pack_b8(b8, out=None):
+    """fp8 B operand (2-D uint8 [N,K]) in the fragment order gemm_fp8(b_packed=...) reads"""
+    _chk(b8, "gemm_pack_b8.b", torch.uint8)
+    n, k = b8.shape
+    if out is None:
+        out = torch.empty(n * k, dtype=torch.uint8, device=b8.device)
+    _chk(out, "gemm_pack_b8.out", torch.uint8, (n * k,))
+    L.check(L.load().ilvlm_gemm_pack_b8(n, k, b8.data_ptr(), b8.stride(0), out.data_ptr(), _stream()), "gemm_pack_b8")
     return out
 
 

@@ -76,6 +76,78 @@ def test_fp8_gemm_matches_dequantised_product(M, N, K, a_e5m2):
     assert float((z.cpu() - (pre + res.cpu())).abs().max()) < 1e-4 * float((pre + res.cpu()).abs().max())
 
 
+def _pack_b8_host(w8):
+    """the layout include/ilvlm_hip.h documents for ilvlm_gemm_pack_b8, restated with numpy indexing"""
+    n, k = w8.shape
+    v = w8.numpy().reshape(n // 16, 16, k // 128, 2, 4, 16)       # [n16, row, k128, half, g, byte]
+    return torch.from_numpy(np.ascontiguousarray(v.transpose(0, 2, 3, 4, 1, 5))).reshape(-1)   # [n16, k128, half, g, row, byte]
+
+
+@pytest.mark.parametrize("a_e5m2", [False, True])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 128), (300, 208, 256), (1000, 768, 768), (77, 512, 3072), (12800, 2304, 768),
+                                   (11319, 512, 2048), (1, 16, 128)])
+def test_fp8_streaming_kernel_equals_the_direct_to_lds_kernel(M, N, K, a_e5m2):
+    """b_packed with fp8 operands: the streaming kernel (A through the LDS ring, fragment-order B straight into the operand
+    registers of the scaled MFMA) performs the same MFMA sequence per output element as the direct-to-LDS kernel on the
+    row-major operand -- bit-identical outputs, every epilogue, ragged M, N not a multiple of the tile width; the packed
+    layout equals the one the header documents"""
+    from ilvlm_amd import ops
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05
+    if a_e5m2:
+        a = a * 1e-4
+    sa, sw = F8[a_e5m2][1] / float(a.abs().max()), 448.0 / float(w.abs().max())
+    a8, w8 = to_f8(a, sa, a_e5m2).view(torch.uint8), to_f8(w, sw, False).view(torch.uint8)
+    inv_a, inv_w = torch.tensor([1.0 / sa], device="cuda"), torch.tensor([1.0 / sw], device="cuda")
+    # A sits in front of poison rows: the streaming kernel must not read past row M
+    Abuf = torch.full((M + 130, K), 0x7b, dtype=torch.uint8, device="cuda"); Abuf[:M] = a8.cuda()
+    A, W = Abuf[:M], w8.cuda()
+    Wp = ops.gemm_pack_b8(W)
+    assert torch.equal(Wp.cpu(), _pack_b8_host(w8))
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    for kw, dt_ in ((dict(), torch.float32), (dict(), torch.bfloat16), (dict(bias=bias, act=1), torch.bfloat16),
+                    (dict(bias=bias, residual=res), torch.float32)):
+        outs = []
+        for bp in (None, Wp):
+            y = torch.full((M, N), float("nan"), device="cuda").to(dt_)
+            k2 = dict(kw)
+            if "act" in k2:
+                k2["aux"] = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ops.gemm_fp8(A, W, y, inv_a, inv_w, a_e5m2=a_e5m2, b_packed=bp, **k2)
+            outs.append((y, k2.get("aux")))
+        assert torch.equal(outs[0][0], outs[1][0]) and not bool(torch.isnan(outs[1][0].float()).any())
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], outs[1][1])
+    ref = (a8.view(F8[a_e5m2][0]).float() @ w8.view(torch.float8_e4m3fn).float().t()) / (sa * sw)
+    assert float((outs[0][0].cpu() - bias.cpu() - res.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
+
+
+def test_packed_weight_quantiser_writes_the_fragment_order_copies():
+    """ilvlm_fp8_quantize_weights_packed: W8 / W8T as the plain call, W8P / W8TP = ilvlm_gemm_pack_b8 of them"""
+    from ilvlm_amd import lib as L, ops
+    shapes = [(128, 384), (256, 128), (384, 256)]
+    offs, o = [], 0
+    for r, c in shapes:
+        offs.append(o)
+        o += r * c + 64
+    P = (rnd(o, seed=5) * 0.3).cuda()
+    table = [[off // 64, r, c, slot, r0, c0] for slot, ((r, c), off) in enumerate(zip(shapes, offs))
+             for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+    tab = torch.tensor(table, dtype=torch.int32).cuda()
+    scale = torch.tensor([100.0, 50.0, 200.0], device="cuda")
+    bufs = [torch.zeros(o, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    am1, am2 = torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda")
+    h, st = L.load(), torch.cuda.current_stream().cuda_stream
+    L.check(h.ilvlm_fp8_quantize_weights(P.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), tab.data_ptr(), len(table),
+                                         scale.data_ptr(), am1.data_ptr(), st), "quantize_weights")
+    L.check(h.ilvlm_fp8_quantize_weights_packed(P.data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(), bufs[4].data_ptr(),
+                                                bufs[5].data_ptr(), tab.data_ptr(), len(table), scale.data_ptr(), am2.data_ptr(), st),
+            "quantize_weights_packed")
+    assert torch.equal(bufs[0], bufs[2]) and torch.equal(bufs[1], bufs[3]) and torch.equal(am1, am2)
+    for (r, c), off in zip(shapes, offs):
+        assert torch.equal(bufs[4][off:off + r * c], ops.gemm_pack_b8(bufs[2][off:off + r * c].view(r, c)))
+        assert torch.equal(bufs[5][off:off + r * c], ops.gemm_pack_b8(bufs[3][off:off + r * c].view(c, r)))
+
+
 @pytest.mark.parametrize("T,M,N,split", [(128, 128, 128, 1), (256, 64, 192, 2), (1000, 768, 768, 3), (11319, 512, 2048, 8),
                                          (77, 16, 48, 1)])
 def test_fp8_weight_gradient_gemm(T, M, N, split):
