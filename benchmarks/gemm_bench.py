@@ -11,13 +11,15 @@ from ilvlm_amd import ops
 
 # selectors timed side by side (GEMM_BENCH_VARIANTS=5,15 by default).  A selector may carry settings of the persistent streaming
 # kernel: "15:s1000:e2:g256" = selector 15 with a start stagger of 1000 cycles per K-tile, epilogue placement 2, 256 workgroups;
-# "15:t96" = 96-row tiles of the streaming kernel (t128 / t64 likewise; t0 = the per-launch cost model; default 128)
+# "15:t96" = 96-row tiles of the streaming kernel (t128 / t64 likewise; t0 = the per-launch cost model; default 128);
+# "15:w256" = 256 x 128 workgroup tiles of the weight-gradient kernel (w257: single-stage), ":m2" = twice the K-slices, ":b1" = the
+# weight gradients' K-slices through the slab workspace (what the engine offers) instead of atomics
 VARIANT_SPECS = os.environ.get("GEMM_BENCH_VARIANTS", "5,15").split(",")
 
 
 def _parse(spec):
     parts = spec.split(":")
-    d = dict(v=int(parts[0]), s=-1, e=-1, g=0, t=-1)
+    d = dict(v=int(parts[0]), s=-1, e=-1, g=0, t=-1, w=-1, m=1, b=0)
     for q in parts[1:]:
         d[q[0]] = int(q[1:])
     return d
@@ -32,6 +34,7 @@ def select(spec):
     ops.gemm_set_variant(d["v"])
     ops.gemm_set_persistent(d["g"], d["e"], d["s"])
     ops.gemm_set_tile_rows(d["t"])
+    ops.gemm_set_wgrad_tile(d["w"])
     return d["v"]
 SHAPES = []   # (tag, ta, tb, M, N, K, accumulate, split)
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
@@ -68,8 +71,9 @@ def run(rounds=7, only=None, epi=False, sk=True):
                 flush.zero_()            # cold caches, as inside a train step
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split,
-                         b_packed=packed if v >= 15 else None, slab=slab if (v in (15, 17) and not acc) else None, **kw)
+                ops.gemm(a, b, out, trans_a=bool(ta), trans_b=bool(tb), accumulate=acc, split_k=split * (VSET[spec]["m"] if acc else 1),
+                         b_packed=packed if v >= 15 else None,
+                         slab=slab if ((v in (15, 17) and not acc) or (acc and VSET[spec]["b"])) else None, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
@@ -83,6 +87,7 @@ def run(rounds=7, only=None, epi=False, sk=True):
     ops.gemm_set_variant(15)
     ops.gemm_set_persistent(0, -1, -1)
     ops.gemm_set_tile_rows(-1)
+    ops.gemm_set_wgrad_tile(-1)
     print("sum of best times: " + ", ".join("v%s %.1f us" % (v, tot[v] * 1e3) for v in VARIANTS))
 
 

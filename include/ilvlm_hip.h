@@ -146,6 +146,12 @@ int ilvlm_gemm_set_persistent(int slots, int epi_sep, int stagger);
  * (DESIGN.md section 6, round 4), hence the default.  Results do not depend on the height (same MFMA sequence per output
  * element).  Tuning / test hook, process-wide atomic. */
 int ilvlm_gemm_set_tile_rows(int rows);
+/* Workgroup tile of the bf16 weight-gradient kernel ((1,1) layout, accumulate): 128 = 128 x 128 (four waves of 64 x 64, two-stage
+ * operand ring; the default), 256 = 256 x 128 (four waves of 128 x 64: a quarter fewer LDS-DMA pieces and transposing fragment
+ * reads per MFMA; two stages, 96 KiB of LDS), 257 = the same tile single-stage (48 KiB); taken when M % 256 == 0.  -1 = default
+ * (ILVLM_WGRAD_TILE).  Same K-slices, same order of K-tiles per output element: results equal the 128 x 128 tile's bit for bit at
+ * one K-slice or with the slab workspace.  Tuning / test hook, process-wide atomic. */
+int ilvlm_gemm_set_wgrad_tile(int rows);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +

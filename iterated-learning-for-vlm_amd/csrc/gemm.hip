@@ -442,30 +442,35 @@ struct DmaOperand {
     // of the reads of a stage, ILVLM_WG_BARRIER).  M0 (the LDS destination) is written and read inside the statement; the
     // instruction between an M0 write and the load is the wait state that pair needs.
     __device__ __forceinline__ void issue(int t, unsigned char* tile, int wave, int extra = 0) const {
-        static_assert(NLOAD == 4, "four 1 KiB pieces per wave and operand (128-row operand, 256 threads)");
+        static_assert(NLOAD == 4 || NLOAD == 8, "four or eight 1 KiB pieces per wave and operand (128 / 256 operand rows, 256 threads)");
         const int soff = tile_off + t * k_step + extra;
         const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)tile + wave * (NLOAD * 1024);
         const pk_i32x4 r4 = rs;
         if constexpr (TR) {
-            asm volatile(
-                "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v3], %[rs], %[so] offen lds"
-                :
-                : [v0] "v"(voff[0]), [v1] "v"(voff[TR ? 1 : 0]), [v2] "v"(voff[TR ? 2 : 0]), [v3] "v"(voff[TR ? 3 : 0]), [rs] "s"(r4),
-                  [so] "s"(soff), [lds] "s"(lds)
-                : "memory", "scc");
+#pragma unroll
+            for (int h = 0; h < NLOAD / 4; ++h)
+                asm volatile(
+                    "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v3], %[rs], %[so] offen lds"
+                    :
+                    : [v0] "v"(voff[TR ? 4 * h : 0]), [v1] "v"(voff[TR ? 4 * h + 1 : 0]), [v2] "v"(voff[TR ? 4 * h + 2 : 0]),
+                      [v3] "v"(voff[TR ? 4 * h + 3 : 0]), [rs] "s"(r4), [so] "s"(soff), [lds] "s"(lds + h * 4096)
+                    : "memory", "scc");
         } else {
-            int tmp;
-            asm volatile(
-                "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[so]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds"
-                : [t] "=&s"(tmp)
-                : [v0] "v"(voff[0]), [rs] "s"(r4), [so] "s"(soff), [js] "s"(jstep), [lds] "s"(lds)
-                : "memory", "scc");
+#pragma unroll
+            for (int h = 0; h < NLOAD / 4; ++h) {
+                int tmp;
+                asm volatile(
+                    "s_mov_b32 m0, %[lds]\n\ts_mov_b32 %[t], %[so]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                    "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t], %[t], %[js]\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t] offen lds"
+                    : [t] "=&s"(tmp)
+                    : [v0] "v"(voff[0]), [rs] "s"(r4), [so] "s"(soff + h * 4 * jstep), [js] "s"(jstep), [lds] "s"(lds + h * 4096)
+                    : "memory", "scc");
+            }
         }
     }
 };
@@ -1181,7 +1186,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
 }
 
 template <bool TA, bool TB, bool SWAP, int DBM, int DBN, int WM, int WN, int NSTAGE, int BKT, int FP8 = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
+__global__ __launch_bounds__(64 * WM * WN, (DBM * DBN > 128 * 128 && WM * WN == 4) ? 2 : (WM * WN == 4 ? (SWAP ? 4 : 3) : (NSTAGE == 1 ? (SWAP ? 4 : 3) : 2))) void gemm_bf16_dma_kernel(const bf16* __restrict__ A, int lda,
                                                                      const bf16* __restrict__ B, int ldb, int K, int tiles_m,
                                                                      int tiles_n, int split_k, EpiArgs ep) {
     dma_gemm_body<TA, TB, SWAP, DBM, DBN, WM, WN, NSTAGE, BKT, FP8>(A, lda, B, ldb, K, tiles_m, tiles_n, split_k, ep,
@@ -2120,6 +2125,7 @@ int launch_pk8(const void* A8, int lda, const void* Bp8, int K, int M, int N, co
     return ILVLM_OK;
 }
 
+std::atomic<int> g_wgrad_tile{-1};    // -1 = ILVLM_WGRAD_TILE (default 128); 128, 256 (two-stage 256 x 128) or 257 (single-stage 256 x 128)
 std::atomic<int> g_pk_ti{-1};         // -1 = ILVLM_PK_TI (default 8); 8, 6, 4 force a tile height, 0 = the cost model (tests, A/B)
 
 // Tile height of a streaming launch (round 4).  A launch takes rounds x (time of one tile): the tiles of a round run side by
@@ -2295,15 +2301,15 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     // the slabs up, and the workspace holds tiles x split slabs
     void* const slab_ws = epi->splitk_ws;
     ep.e.splitk_ws = nullptr;
-    auto slab_setup = [&](int k_tile) {
+    auto slab_setup = [&](int k_tile, int tile_m = 128) {
         if (!slab_ws || !epi->splitk_cnt || !epi->accumulate || split_k <= 1) return;
         static const int max_split = getenv("ILVLM_SLAB_MAX_SPLIT") ? atoi(getenv("ILVLM_SLAB_MAX_SPLIT")) : 8;
         const int nt_ = ceil_div(K, k_tile);
         int sk = split_k < nt_ ? split_k : nt_;
         while (sk > 1 && (long)(sk - 1) * ceil_div(nt_, sk) >= nt_) --sk;
-        const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-        if (sk > 1 && sk <= max_split && tiles <= epi->splitk_cnt_len && tiles * sk * (128L * 128 * 4) <= epi->splitk_ws_bytes &&
-            tiles * sk * (128L * 128 * 4) < (1L << 31)) {
+        const long tiles = (long)ceil_div(M, tile_m) * ceil_div(N, 128), slab = (long)tile_m * 128 * 4;
+        if (sk > 1 && sk <= max_split && tiles <= epi->splitk_cnt_len && tiles * sk * slab <= epi->splitk_ws_bytes &&
+            tiles * sk * slab < (1L << 31)) {
             split_k = sk;
             ep.e.splitk_ws = slab_ws;
         }
@@ -2416,6 +2422,20 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU
+            // weight gradients on 256 x 128 workgroup tiles, 128 x 64 per wave (round 4, opt-in: ILVLM_WGRAD_TILE=256 /
+            // ilvlm_gemm_set_wgrad_tile): 48 KiB of operands per K-tile for twice the MFMAs of the 128 x 128 tile's 32 KiB -- a quarter
+            // fewer LDS-DMA pieces and transposing fragment reads per MFMA; 96 KiB (two stages) or 48 KiB (one) of LDS
+            static const int wg_tile_env = getenv("ILVLM_WGRAD_TILE") ? atoi(getenv("ILVLM_WGRAD_TILE")) : 128;
+            static const int wg_tile_mul = getenv("ILVLM_WGRAD_TILE_SPLIT_MUL") ? atoi(getenv("ILVLM_WGRAD_TILE_SPLIT_MUL")) : 1;
+            const int wg_sel = g_wgrad_tile.load(std::memory_order_relaxed);
+            const int wg_tile = wg_sel < 0 ? wg_tile_env : wg_sel;
+            if (!swap && trans_a && trans_b && variant >= 15 && (wg_tile == 256 || wg_tile == 257) && M % 256 == 0) {
+                split_k *= wg_tile_mul;
+                if (split_k > nt) split_k = nt;
+                slab_setup(64, 256);
+                if (wg_tile == 257) return launch_dma<true, true, false, 256, 128, 2, 2, 1>(a, lda, b, ldb, K, M, N, split_k, ep, s);
+                return launch_dma<true, true, false, 256, 128, 2, 2, 2>(a, lda, b, ldb, K, M, N, split_k, ep, s);
+            }
             if (!swap) slab_setup(64);
             // weight gradients (both operands K-strided, accumulate): two-stage operand ring -- K-tile t+1 is in flight while
             // t is multiplied (64 KiB of LDS, two workgroups per CU).  Round 2 measured this form 3 % SLOWER; that build
@@ -2460,6 +2480,14 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     if (!trans_a && trans_b) return launch_f32<false, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     if (trans_a && !trans_b) return launch_f32<true, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     return launch_f32<true, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+}
+
+// tuning / test hook: workgroup tile of the bf16 weight-gradient kernel (-1 = default / ILVLM_WGRAD_TILE, 128, 256 = 256 x 128
+// two-stage, 257 = 256 x 128 single-stage)
+extern "C" int ilvlm_gemm_set_wgrad_tile(int rows) {
+    ILVLM_REQUIRE(rows == -1 || rows == 128 || rows == 256 || rows == 257, "gemm_set_wgrad_tile: -1, 128, 256 or 257");
+    g_wgrad_tile.store(rows, std::memory_order_relaxed);
+    return ILVLM_OK;
 }
 
 // tuning hook for the benchmarks/tests: selects the bf16 kernel variant (see g_gemm_variant)

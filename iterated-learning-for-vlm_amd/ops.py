@@ -355,6 +355,11 @@ def gemm_set_tile_rows(rows=-1):
     L.check(L.load().ilvlm_gemm_set_tile_rows(int(rows)), "gemm_set_tile_rows")
 
 
+def gemm_set_wgrad_tile(rows=-1):
+    """bf16 weight-gradient kernel: workgroup tile 128 (128 x 128), 256 (256 x 128, two stages), 257 (256 x 128, one stage), -1 = default"""
+    L.check(L.load().ilvlm_gemm_set_wgrad_tile(int(rows)), "gemm_set_wgrad_tile")
+
+
 def gemm_set_persistent(slots=0, epi_sep=-1, stagger=-1):
     """persistent streaming kernel: workgroups per launch (0 = two per CU), epilogue LDS placement (-1 = default) and the start
     delay of each CU's second workgroup in cycles per K-tile (-1 = default)"""

@@ -941,6 +941,39 @@ def test_weight_gradient_gemm_at_full_size(M, N, K, split):
         assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
 
 
+@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("M,N,K,split", [(3072, 768, 12800, 3), (768, 3072, 12800, 1), (2304, 768, 12800, 4), (2048, 512, 11319, 6),
+                                         (256, 128, 256, 1), (512, 200, 1000, 5), (1536, 512, 11319, 1)])
+def test_weight_gradient_on_256_row_tiles_equals_the_128_row_tiles(M, N, K, split, tile):
+    """the 256 x 128 workgroup tile of the weight-gradient kernel (128 x 64 per wave; two stages / one stage): same K-slices and
+    the same K-tile order per output element as the 128 x 128 tile -- bit-identical at one K-slice and through the slab
+    workspace, within the atomics' reordering otherwise; ragged reduction lengths and N; row sums (bias gradient) included"""
+    ops = _ops()
+    a, b = rnd(K, M, seed=1).to(torch.bfloat16).cuda(), rnd(K, N, seed=2).to(torch.bfloat16).cuda()
+    ref = a.float().t() @ b.float()
+    rs_ref = a.float().sum(0)
+    scale = float(ref.abs().max())
+    slab = (torch.empty(64 << 20, dtype=torch.uint8, device="cuda"), torch.zeros(4096, dtype=torch.int32, device="cuda"))
+    slab[0].fill_(0xff)
+    base = rnd(M, N, seed=5).cuda() * scale
+    res = {}
+    try:
+        for t in (128, tile):
+            ops.gemm_set_wgrad_tile(t)
+            for use_slab in (False, True):
+                out, rs = base.clone(), torch.zeros(M, device="cuda")
+                ops.gemm(a, b, out, trans_a=True, trans_b=True, accumulate=True, split_k=split, a_rowsum=rs, slab=slab if use_slab else None)
+                assert float((out - base - ref).abs().max()) < 1e-3 * scale
+                assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
+                res[(t, use_slab)] = out
+    finally:
+        ops.gemm_set_wgrad_tile(-1)
+    assert int(slab[1].abs().sum()) == 0
+    if split == 1:
+        assert torch.equal(res[(128, False)], res[(tile, False)])
+    assert torch.equal(res[(128, True)], res[(tile, True)])
+
+
 @pytest.mark.parametrize("M,N,K,split", [(3072, 768, 12800, 3), (768, 3072, 12800, 3), (2304, 768, 12800, 4), (2048, 512, 11319, 6),
                                          (304, 200, 1000, 5), (128, 128, 256, 4), (1536, 512, 11319, 8)])
 def test_slab_split_k_weight_gradient_is_right_and_bit_reproducible(M, N, K, split):
