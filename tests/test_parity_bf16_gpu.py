@@ -153,6 +153,9 @@ GRAD_SAMPLE_B32 = ("space_dict", "visual.transformer.resblocks.0.attn.in_proj_we
                    "img_query_model.q_map.1.weight", "txt_query_model.q_map.4.bias", "txt_query_model.q_map.0.weight")
 
 
+COS_MARGIN, NORM_MARGIN = 0.01, 0.03
+
+
 def _real_size_step(factory, kwargs, heads, B, seed, grad_sample, threads=None):
     """one bf16 HIP step and one fp32 oracle step (forward + backward) of a real-size model on the same weights / batch"""
     from ilvlm_amd.prototype.model import model_entry
@@ -168,6 +171,14 @@ def _real_size_step(factory, kwargs, heads, B, seed, grad_sample, threads=None):
     o = O.clip_fdt_forward(p, torch.from_numpy(img), torch.from_numpy(tok), torch.from_numpy(mask), cfg)
     loss_ref, _ = O.info_nce(o["logits_i"], o["logits_t"])
     loss_ref.backward()
+    # control: the SAME oracle with every matrix-product operand rounded to bf16 (fp32 sums) -- what the compute dtype itself does
+    # to these gradients; the HIP path is held to it below (a kernel that scales a gradient by a few per cent fails, rounding passes)
+    pc = {k: v.detach().clone().requires_grad_(k in grad_sample) for k, v in model.state_dict().items()}
+    with O.rounding(O.bf16_ste):
+        oc = O.clip_fdt_forward(pc, torch.from_numpy(img), torch.from_numpy(tok), torch.from_numpy(mask), cfg)
+        loss_c, _ = O.info_nce(oc["logits_i"], oc["logits_t"])
+        loss_c.backward()
+    o["control_grads"] = {n: pc[n].grad.detach() for n in grad_sample}
     model.cuda().train()
     texts = (torch.from_numpy(tok), torch.from_numpy(mask))
     (li, lt), _ = model(torch.from_numpy(img).cuda(), texts)
@@ -207,6 +218,21 @@ def _check_real_size(tag, model, p, o, loss_ref, li, lt, loss, emb, grad_sample)
     for n in grad_sample:
         assert coss[n] > 0.98, "bf16 gradient direction of %s: cos %.4f" % (n, coss[n])
         assert 0.9 < mags[n] < 1.1, "bf16 gradient norm of %s: ratio %.3f" % (n, mags[n])
+    # against the operand-rounding control (round 4; the verdict: "would not catch a 5 % scaling bug in one kernel"): the HIP
+    # gradient may point no worse at the fp32 oracle's than the control's does minus COS_MARGIN, its norm may differ from the
+    # control's by NORM_MARGIN, and it must agree with the control itself in direction
+    ctl = o["control_grads"]
+    c_cos = {n: cosine(ctl[n], p[n].grad) for n in grad_sample}
+    c_mag = {n: float(ctl[n].norm() / p[n].grad.norm()) for n in grad_sample}
+    hc_cos = {n: cosine(got[n].grad, ctl[n]) for n in grad_sample}
+    worst = max(grad_sample, key=lambda n: abs(mags[n] / c_mag[n] - 1.0))
+    print("%s: control (bf16-operand oracle) cosines min %.4f, norm ratios %.3f..%.3f; HIP vs control: cosine min %.4f (%s), "
+          "largest norm difference %.3f (%s)" % (tag, min(c_cos.values()), min(c_mag.values()), max(c_mag.values()),
+                                                 min(hc_cos.values()), min(hc_cos, key=hc_cos.get),
+                                                 abs(mags[worst] / c_mag[worst] - 1.0), worst))
+    for n in grad_sample:
+        assert coss[n] >= c_cos[n] - COS_MARGIN, "bf16 gradient of %s: cos %.4f, the dtype's own (control) %.4f" % (n, coss[n], c_cos[n])
+        assert abs(mags[n] / c_mag[n] - 1.0) < NORM_MARGIN, "bf16 gradient norm of %s: %.3f x the control's" % (n, mags[n] / c_mag[n])
 
 
 def test_vitb32_fdt_bf16_batch256_matches_oracle():
