@@ -337,13 +337,15 @@ int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, const unsigned 
 /* ---- input pipeline, the random augmentations: MOCOV2_single of prototype/data/imagenet_dataloader.py:59-68
  * (RandomResizedCrop, ColorJitter @ 0.8, RandomGrayscale, GaussianBlur @ 0.5, RandomHorizontalFlip, ToTensor, Normalize) from
  * DECODED uint8 images of any size.  The random draws are made on the host (what torchvision's get_params return, one
- * ilvlm_augment_params per sample); the pixel work -- antialiased bilinear resize of the crop box to out_size x out_size, the
- * four colour operations in the drawn order with PIL's integer luma / blend / HSV arithmetic, luma replacement, separable
- * Gaussian blur, flip, normalise -- runs on the device.  src: the images back to back as [H][W][3] uint8, image b at byte
+ * ilvlm_augment_params per sample); the pixel work runs on the device in PIL's own arithmetic -- the crop box resampled to
+ * out_size x out_size as Image.resize(BILINEAR) does it (8-bit fixed point, an 8-bit image between the two passes), the four
+ * colour operations in the drawn order with PIL's integer luma / blend / HSV arithmetic, luma replacement, the box-blur passes
+ * behind ImageFilter.GaussianBlur(radius = sigma) (prototype/data/transforms.py:82-91), flip, float32 ToTensor / Normalize --
+ * so that, given the same draws, dst equals what the reference's loader workers produce bit for bit.  src: the images back to back as [H][W][3] uint8, image b at byte
  * src_offsets[b] with src_hw[2b], src_hw[2b+1] = its height, width (device arrays; the crop box must lie inside the image);
  * dst: fp32 [B,3,out_size,out_size]; scratch: ilvlm_image_augment_scratch_floats(B, out_size, max_crop_rows) floats, where
- * max_crop_rows >= every crop_h; mean3 / std3: HOST arrays.  Differences from PIL that remain (fp32 resampling and a true
- * Gaussian instead of 8-bit fixed point and box-blur passes): csrc/augment.hip; tests/test_input_pipeline_gpu.py. */
+ * max_crop_rows >= every crop_h; mean3 / std3: HOST arrays.  tests/test_augment_cpu.py (restatement = PIL, exactly) and
+ * tests/test_input_pipeline_gpu.py (kernels = restatement, exactly). */
 typedef struct ilvlm_augment_params {
     int crop_top, crop_left, crop_h, crop_w; /* RandomResizedCrop.get_params */
     int jitter;                              /* ColorJitter applied (RandomApply, p = 0.8) */

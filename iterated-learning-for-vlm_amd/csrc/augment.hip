@@ -6,20 +6,22 @@
 // workers cannot keep up with; shard reading and JPEG decode stay with the loader
 // (prototype/data/datasets/clip_dataset_wsd.py:158-240).  The RANDOM DRAWS stay on the host too -- a dozen numbers per sample
 // (ilvlm_augment_params: what torchvision's get_params return) -- the pixel work runs here, per sample:
-//   1. the crop box resized to OUT x OUT: bilinear WITH the antialiasing PIL's resize applies (a triangle filter whose support
-//      grows with the down-scaling factor, taps clipped to the crop box as torchvision crops first), separable: horizontal
-//      pass into a float scratch, vertical pass, rounded to 0..255 as PIL's uint8 result is;
+//   1. the crop box resized to OUT x OUT as PIL's Image.resize(BILINEAR) does it (Resample.c; torchvision crops first, so the
+//      taps are clipped to the crop box): a triangle filter whose support grows with the down-scaling factor, its weights
+//      computed in double and rounded to 22-bit fixed point, a horizontal pass into an 8-bit image, then the vertical pass;
 //   2. the four ColorJitter operations in the drawn order, each as torchvision's F.adjust_* defines it on a PIL image:
 //      ImageEnhance blends with black / the rounded mean of the luma image / the luma image (Image.blend truncates to uint8),
 //      hue through PIL's 8-bit HSV with numpy's uint8 wrap; then RandomGrayscale's luma replacement (PIL "L");
-//   3. Gaussian blur with the drawn sigma (separable, radius ceil(3 sigma), taps outside the image dropped and the rest
-//      renormalised), horizontal flip, / 255, (x - mean) / std, written as fp32 NCHW.
+//   3. the reference's GaussianBlur = ImageFilter.GaussianBlur(radius = sigma) (prototype/data/transforms.py:82-91), i.e.
+//      PIL's approximation by box blurs (BoxBlur.c): a fractional box radius from sigma, three horizontal passes and three
+//      vertical ones in 32-bit fixed point with an 8-bit image after each, edges extended; horizontal flip; ToTensor's
+//      float32 / 255 and Normalize's (x - mean) / std as float32 divisions, written as fp32 NCHW.
 // One workgroup per image for 2-3: the contrast step needs the image's mean luma (a workgroup reduction) and the passes meet
 // at workgroup barriers, the 600 KB working image staying in L2.
-// Differences from PIL that remain, stated rather than hidden: PIL resamples in 8-bit fixed point with a uint8 image between
-// the two passes, and ImageFilter.GaussianBlur approximates the Gaussian by repeated box blurs; here both are fp32 with one
-// rounding.  tests/test_input_pipeline_gpu.py restates exactly the arithmetic above on the CPU (fp32) and bounds the
-// difference; the distribution of augmented images is the reference's.
+// Every stage repeats PIL's own arithmetic operation by operation (no fused multiply-adds where the C code has none), so
+// given the same draws the output equals what the reference's loader workers produce BIT FOR BIT: tests/augment_ref.py restates
+// the same arithmetic with numpy, tests/test_augment_cpu.py holds that restatement to PIL exactly (every stage and the whole
+// chain), tests/test_input_pipeline_gpu.py holds these kernels to the restatement exactly.
 #include "common.h"
 
 namespace {
@@ -34,24 +36,43 @@ __device__ __forceinline__ float luma_pil(float r, float g, float b) {
     return (float)(((int)r * 19595 + (int)g * 38470 + (int)b * 7471 + 0x8000) >> 16);
 }
 
-// PIL's precompute_coeffs for the bilinear (triangle) filter: taps [lo, hi) of output index o, in coordinates of the crop
-struct Taps { int lo, hi; float center, ss, norm; };
+// PIL's precompute_coeffs for the bilinear (triangle) filter + normalize_coeffs_8bpc: taps [xmin, xmin + n) of output index o in
+// coordinates of the crop, weight of tap x as 22-bit fixed point.  The double operations of Resample.c in their order, unfused
+// (fp contract off: the host code PIL is compiled to has no fused multiply-add, and one flipped rounding of a weight shows).
+constexpr int RS_BITS = 32 - 8 - 2;
+struct Taps { int xmin, n; double center, ss, ww; };
+__device__ __forceinline__ double tap_weight(const Taps& t, int x) {
+#pragma clang fp contract(off)
+    double w = ((double)(x + t.xmin) - t.center + 0.5) * t.ss;
+    w = w < 0.0 ? -w : w;
+    return w < 1.0 ? 1.0 - w : 0.0;
+}
 __device__ __forceinline__ Taps taps_of(int o, int in_size, int out_size) {
-    const float scale = (float)in_size / (float)out_size;
-    const float fs = fmaxf(scale, 1.f);                 // antialias when down-scaling
+#pragma clang fp contract(off)
+    const double scale = (double)in_size / (double)out_size;
+    const double fs = scale < 1.0 ? 1.0 : scale;        // antialias when down-scaling; support = 1.0 * filterscale
     Taps t;
-    t.center = ((float)o + 0.5f) * scale;
-    t.ss = 1.f / fs;
-    t.lo = max((int)(t.center - fs + 0.5f), 0);
-    t.hi = min((int)(t.center + fs + 0.5f), in_size);
-    float n = 0.f;
-    for (int x = t.lo; x < t.hi; ++x) n += fmaxf(0.f, 1.f - fabsf(((float)x - t.center + 0.5f) * t.ss));
-    t.norm = n > 0.f ? 1.f / n : 0.f;
+    t.center = ((double)o + 0.5) * scale;
+    t.ss = 1.0 / fs;
+    int xmin = (int)(t.center - fs + 0.5), xmax = (int)(t.center + fs + 0.5);
+    xmin = xmin < 0 ? 0 : xmin;
+    xmax = xmax > in_size ? in_size : xmax;
+    t.xmin = xmin;
+    t.n = xmax - xmin;
+    double ww = 0.0;
+    for (int x = 0; x < t.n; ++x) ww += tap_weight(t, x);
+    t.ww = ww;
     return t;
 }
-__device__ __forceinline__ float tap_w(const Taps& t, int x) { return fmaxf(0.f, 1.f - fabsf(((float)x - t.center + 0.5f) * t.ss)) * t.norm; }
+__device__ __forceinline__ int tap_coef(const Taps& t, int x) {
+#pragma clang fp contract(off)
+    double w = tap_weight(t, x);
+    if (t.ww != 0.0) w = w / t.ww;
+    return (int)(0.5 + w * (double)(1 << RS_BITS));     // weights are non-negative
+}
+__device__ __forceinline__ float rs_clip8(int v) { return (float)min(max(v >> RS_BITS, 0), 255); }
 
-// pass 1: every row of the crop box resampled horizontally: tmp[b][y][ox][c], y in [0, crop_h)
+// pass 1: every row of the crop box resampled horizontally: tmp[b][y][ox][c], y in [0, crop_h), 8-bit values (held as floats)
 __global__ __launch_bounds__(256) void aug_resize_h_kernel(const unsigned char* __restrict__ src, const long* __restrict__ src_off,
                                                            const int* __restrict__ src_hw, const ilvlm_augment_params* __restrict__ prm,
                                                            float* __restrict__ tmp, long tmp_stride, int OUT) {
@@ -63,18 +84,18 @@ __global__ __launch_bounds__(256) void aug_resize_h_kernel(const unsigned char* 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.crop_h * OUT; i += gridDim.x * 256) {
         const int y = i / OUT, ox = i - y * OUT;
         const Taps tp = taps_of(ox, p.crop_w, OUT);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int x = tp.lo; x < tp.hi; ++x) {
-            const float w = tap_w(tp, x);
-            const unsigned char* q = img + ((long)y * W + x) * 3;
-            a0 += w * q[0]; a1 += w * q[1]; a2 += w * q[2];
+        int a0 = 1 << (RS_BITS - 1), a1 = a0, a2 = a0;
+        for (int x = 0; x < tp.n; ++x) {
+            const int k = tap_coef(tp, x);
+            const unsigned char* q = img + ((long)y * W + tp.xmin + x) * 3;
+            a0 += k * q[0]; a1 += k * q[1]; a2 += k * q[2];
         }
         float* o = t + (long)i * 3;
-        o[0] = a0; o[1] = a1; o[2] = a2;
+        o[0] = rs_clip8(a0); o[1] = rs_clip8(a1); o[2] = rs_clip8(a2);
     }
 }
 
-// pass 2: vertical resample -> work[b][oy][ox][c], rounded to 0..255
+// pass 2: vertical resample of the 8-bit intermediate -> work[b][oy][ox][c], 8-bit values
 __global__ __launch_bounds__(256) void aug_resize_v_kernel(const ilvlm_augment_params* __restrict__ prm, const float* __restrict__ tmp,
                                                            long tmp_stride, float* __restrict__ work, int OUT) {
     const int b = blockIdx.y;
@@ -84,15 +105,27 @@ __global__ __launch_bounds__(256) void aug_resize_v_kernel(const ilvlm_augment_p
     for (int i = blockIdx.x * 256 + threadIdx.x; i < OUT * OUT; i += gridDim.x * 256) {
         const int oy = i / OUT, ox = i - oy * OUT;
         const Taps tp = taps_of(oy, p.crop_h, OUT);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int y = tp.lo; y < tp.hi; ++y) {
-            const float w = tap_w(tp, y);
-            const float* q = t + ((long)y * OUT + ox) * 3;
-            a0 += w * q[0]; a1 += w * q[1]; a2 += w * q[2];
+        int a0 = 1 << (RS_BITS - 1), a1 = a0, a2 = a0;
+        for (int y = 0; y < tp.n; ++y) {
+            const int k = tap_coef(tp, y);
+            const float* q = t + ((long)(tp.xmin + y) * OUT + ox) * 3;
+            a0 += k * (int)q[0]; a1 += k * (int)q[1]; a2 += k * (int)q[2];
         }
         float* o = w_ + (long)i * 3;
-        o[0] = round255(a0); o[1] = round255(a1); o[2] = round255(a2);
+        o[0] = rs_clip8(a0); o[1] = rs_clip8(a1); o[2] = rs_clip8(a2);
     }
+}
+
+// _gaussian_blur_radius of BoxBlur.c: the fractional box radius whose three passes approximate a Gaussian of this sigma
+// (float variables, the square root in double, as the C code)
+__device__ __forceinline__ float box_radius_of(float sigma) {
+#pragma clang fp contract(off)
+    const float sigma2 = sigma * sigma / 3.f;
+    const float L = (float)sqrt(12.0 * (double)sigma2 + 1.0);
+    const float l = (float)floor(((double)L - 1.0) / 2.0);
+    float a = (2.f * l + 1.f) * (l * (l + 1.f) - 3.f * sigma2);
+    a = __fdiv_rn(a, 6.f * (sigma2 - (l + 1.f) * (l + 1.f)));
+    return l + a;
 }
 
 __device__ __forceinline__ double aug_block_sum_d(double v, double* sh) {
@@ -148,12 +181,11 @@ __device__ __forceinline__ void adjust_hue(float& r, float& g, float& b, float h
     }
 }
 
-// colour jitter, grayscale, blur, flip, normalise: one workgroup per image; work [OUT][OUT][3] in place, blur through tmp
+// colour jitter, grayscale, blur, flip, normalise: one workgroup per image; work [OUT][OUT][3] in place, blur passes alternate with tmp
 __global__ __launch_bounds__(AUG_THREADS) void aug_color_kernel(const ilvlm_augment_params* __restrict__ prm, float* __restrict__ work,
                                                                 float* __restrict__ tmp, long tmp_stride, float* __restrict__ dst, int OUT,
-                                                                float m0, float m1, float m2, float is0, float is1, float is2) {
+                                                                float m0, float m1, float m2, float sd0, float sd1, float sd2) {
     __shared__ double shd[AUG_THREADS / 64];
-    __shared__ float gk[32];
     const int b = blockIdx.x, npix = OUT * OUT;
     const ilvlm_augment_params p = prm[b];
     float* w = work + (long)b * npix * 3;
@@ -193,28 +225,32 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_color_kernel(const ilvlm_augm
     }
     __threadfence_block();
     __syncthreads();
-    if (p.blur_sigma > 0.f) {
-        const int rad = min((int)ceilf(3.f * p.blur_sigma), 15);
-        if ((int)threadIdx.x <= rad) gk[threadIdx.x] = expf(-0.5f * (float)(threadIdx.x * threadIdx.x) / (p.blur_sigma * p.blur_sigma));
-        __syncthreads();
-        // horizontal into tmp, vertical back into work
-        for (int pass = 0; pass < 2; ++pass) {
-            const float* in = pass == 0 ? w : t;
-            float* out = pass == 0 ? t : w;
+    const float fr = p.blur_sigma > 0.f ? box_radius_of(p.blur_sigma) : 0.f;
+    if (fr != 0.f) {
+        // ImagingBoxBlur: three passes along x, then three along y; a pass = ImagingLineBoxBlur: the 2 r + 1 window with weight ww,
+        // the two pixels just beyond it with fw, edge pixels repeated, 32-bit unsigned arithmetic, (bulk + 2^23) >> 24
+        const int r = (int)fr;
+        const unsigned ww = (unsigned)__fdiv_rn(16777216.f, __fadd_rn(__fmul_rn(fr, 2.f), 1.f));
+        const unsigned fw = ((1u << 24) - (unsigned)(r * 2 + 1) * ww) / 2u;
+        for (int pass = 0; pass < 6; ++pass) {
+            const float* in = (pass & 1) ? t : w;         // w -> t -> w -> t -> w -> t -> w: the sixth pass ends in `work`
+            float* out = (pass & 1) ? w : t;
+            const bool along_x = pass < 3;
             for (int i = threadIdx.x; i < npix; i += AUG_THREADS) {
                 const int y = i / OUT, x = i - y * OUT;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, n = 0.f;
-                for (int d = -rad; d <= rad; ++d) {
-                    const int xx = pass == 0 ? x + d : x, yy = pass == 0 ? y : y + d;
-                    if (xx < 0 || xx >= OUT || yy < 0 || yy >= OUT) continue;
-                    const float wgt = gk[d < 0 ? -d : d];
-                    const float* q = in + ((long)yy * OUT + xx) * 3;
-                    a0 += wgt * q[0]; a1 += wgt * q[1]; a2 += wgt * q[2]; n += wgt;
+                const int pos = along_x ? x : y;
+                const long base = along_x ? (long)y * OUT * 3 : (long)x * 3, step = along_x ? 3 : (long)OUT * 3;
+                unsigned a0 = 0, a1 = 0, a2 = 0;
+                for (int d = -r; d <= r; ++d) {
+                    const float* q = in + base + (long)min(max(pos + d, 0), OUT - 1) * step;
+                    a0 += (unsigned)q[0]; a1 += (unsigned)q[1]; a2 += (unsigned)q[2];
                 }
-                const float inv = 1.f / n;
+                const float* ql = in + base + (long)max(pos - r - 1, 0) * step;
+                const float* qr = in + base + (long)min(pos + r + 1, OUT - 1) * step;
                 float* o = out + (long)i * 3;
-                if (pass == 0) { o[0] = a0 * inv; o[1] = a1 * inv; o[2] = a2 * inv; }
-                else { o[0] = round255(a0 * inv); o[1] = round255(a1 * inv); o[2] = round255(a2 * inv); }
+                o[0] = (float)((a0 * ww + ((unsigned)ql[0] + (unsigned)qr[0]) * fw + (1u << 23)) >> 24);
+                o[1] = (float)((a1 * ww + ((unsigned)ql[1] + (unsigned)qr[1]) * fw + (1u << 23)) >> 24);
+                o[2] = (float)((a2 * ww + ((unsigned)ql[2] + (unsigned)qr[2]) * fw + (1u << 23)) >> 24);
             }
             __threadfence_block();
             __syncthreads();
@@ -225,9 +261,10 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_color_kernel(const ilvlm_augm
         const int y = i / OUT, x = i - y * OUT;
         const int xs = p.flip ? OUT - 1 - x : x;
         const float* q = w + ((long)y * OUT + xs) * 3;
-        d[i] = (q[0] * (1.f / 255.f) - m0) * is0;
-        d[npix + i] = (q[1] * (1.f / 255.f) - m1) * is1;
-        d[2 * npix + i] = (q[2] * (1.f / 255.f) - m2) * is2;
+        // ToTensor: float32 value / 255; Normalize: (x - mean) / std -- float32 divisions, as torchvision's tensor ops
+        d[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(q[0], 255.f), m0), sd0);
+        d[npix + i] = __fdiv_rn(__fsub_rn(__fdiv_rn(q[1], 255.f), m1), sd1);
+        d[2 * npix + i] = __fdiv_rn(__fsub_rn(__fdiv_rn(q[2], 255.f), m2), sd2);
     }
 }
 
@@ -254,7 +291,7 @@ extern "C" int ilvlm_image_augment(const unsigned char* src, const long* src_off
     hipLaunchKernelGGL(aug_resize_v_kernel, dim3(32, B), dim3(256), 0, s, params, tmp, tmp_stride, work, out_size);
     ILVLM_LAUNCH_CHECK("image_augment (vertical resample)");
     hipLaunchKernelGGL(aug_color_kernel, dim3(B), dim3(AUG_THREADS), 0, s, params, work, tmp, tmp_stride, dst, out_size, mean3[0], mean3[1],
-                       mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+                       mean3[2], std3[0], std3[1], std3[2]);
     ILVLM_LAUNCH_CHECK("image_augment (colour / blur / normalise)");
     return ILVLM_OK;
 }

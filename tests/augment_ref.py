@@ -1,24 +1,94 @@
-"""Float CPU restatement of the augmentation arithmetic the device kernels implement (csrc/augment.hip): MOCOV2_single of the
-reference (prototype/data/imagenet_dataloader.py:59-68) after decode.  Test infrastructure: tests/test_augment_cpu.py pins it
-against PIL (the library torchvision's transforms call for PIL images, i.e. what the reference's loader workers run);
-tests/test_input_pipeline_gpu.py compares the kernels with it."""
+"""CPU restatement of the augmentation arithmetic the device kernels implement (csrc/augment.hip): MOCOV2_single of the
+reference (prototype/data/imagenet_dataloader.py:59-68) after decode, in PIL's own arithmetic -- 8-bit fixed-point resampling
+(Resample.c), Image.blend / "L" / HSV for the colour operations, the box-blur passes behind ImageFilter.GaussianBlur
+(BoxBlur.c), then ToTensor / Normalize in float32.  Test infrastructure: tests/test_augment_cpu.py pins it against PIL (the
+library torchvision's transforms call for PIL images, i.e. what the reference's loader workers run) -- EXACTLY, every stage;
+tests/test_input_pipeline_gpu.py compares the kernels with it, bit for bit."""
 import numpy as np
 
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
-# truncation, PIL's "L" luma and 8-bit HSV, a separable Gaussian with renormalised borders, flip, ToTensor, Normalize
+PRECISION_BITS = 32 - 8 - 2
+
+
 def _coeffs(in_size, out_size):
-    scale = in_size / out_size
+    """PIL's precompute_coeffs (bilinear = triangle filter, support 1, widened by the down-scaling factor) followed by
+    normalize_coeffs_8bpc: per output index the first tap and the taps' weights as 22-bit fixed point.  Every operation is the
+    C double operation of Resample.c, in its order (the kernels repeat them with unfused intrinsics)."""
+    scale = float(in_size) / float(out_size)
     fs = max(scale, 1.0)
+    ss = 1.0 / fs
     out = []
-    for o in range(out_size):
-        center = (o + 0.5) * scale
-        lo = max(int(center - fs + 0.5), 0)
-        hi = min(int(center + fs + 0.5), in_size)
-        w = np.maximum(0.0, 1.0 - np.abs((np.arange(lo, hi) - center + 0.5) / fs))
-        out.append((lo, hi, w / w.sum()))
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - fs + 0.5), 0)
+        xmax = min(int(center + fs + 0.5), in_size)
+        k, ww = [], 0.0
+        for x in range(xmax - xmin):
+            w = (x + xmin - center + 0.5) * ss
+            w = -w if w < 0.0 else w
+            w = 1.0 - w if w < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        ki = [int(0.5 + (w / ww if ww != 0.0 else w) * (1 << PRECISION_BITS)) for w in k]       # weights are >= 0: (int)(0.5 + ...)
+        out.append((xmin, np.array(ki, dtype=np.int64)))
     return out
+
+
+def _clip8(v):
+    return np.clip(v >> PRECISION_BITS, 0, 255)
+
+
+def resize_pil(img, out):
+    """Image.resize((out, out), BILINEAR) of a uint8 [h, w, 3] image: horizontal pass into a uint8 image, then vertical"""
+    a = img.astype(np.int64)
+    half = 1 << (PRECISION_BITS - 1)
+    tmp = np.empty((a.shape[0], out, 3), dtype=np.int64)
+    for ox, (xmin, k) in enumerate(_coeffs(a.shape[1], out)):
+        tmp[:, ox] = _clip8(half + np.tensordot(a[:, xmin:xmin + len(k)], k, axes=(1, 0)))
+    res = np.empty((out, out, 3), dtype=np.int64)
+    for oy, (ymin, k) in enumerate(_coeffs(a.shape[0], out)):
+        res[oy] = _clip8(half + np.tensordot(k, tmp[ymin:ymin + len(k)], axes=(0, 0)))
+    return res
+
+
+def box_radius(sigma, passes=3):
+    """_gaussian_blur_radius of BoxBlur.c (float variables, the square root in double)"""
+    f = np.float32
+    sigma = f(sigma)
+    sigma2 = f(sigma * sigma / f(passes))
+    L = f(np.sqrt(12.0 * np.float64(sigma2) + 1.0))
+    l = f(np.floor((np.float64(L) - 1.0) / 2.0))
+    a = f(f(f(2) * l + f(1)) * f(f(l * f(l + f(1))) - f(f(3) * sigma2)))
+    a = f(a / f(f(6) * f(sigma2 - f(f(l + f(1)) * f(l + f(1))))))
+    return f(l + a)
+
+
+def _box_blur(a, fr):
+    """ImagingLineBoxBlur along axis 0: the 2 r + 1 window with weight ww, the two pixels beyond it with fw, edges extended,
+    32-bit unsigned arithmetic, (bulk + 2^23) >> 24"""
+    n, r = a.shape[0], int(fr)
+    ww = int(np.float32(16777216.0) / np.float32(np.float32(fr) * np.float32(2) + np.float32(1)))
+    fw = (((1 << 24) - (r * 2 + 1) * ww) & 0xffffffff) // 2
+    idx = np.arange(n)
+    acc = sum(a[np.clip(idx + d, 0, n - 1)] for d in range(-r, r + 1))
+    far = a[np.clip(idx - r - 1, 0, n - 1)] + a[np.clip(idx + r + 1, 0, n - 1)]
+    return ((((acc * ww + far * fw) & 0xffffffff) + (1 << 23)) & 0xffffffff) >> 24
+
+
+def gaussian_blur_pil(a, sigma, passes=3):
+    """ImageFilter.GaussianBlur(radius=sigma): three horizontal box blurs, then three vertical (ImagingBoxBlur)"""
+    fr = box_radius(sigma, passes)
+    a = a.astype(np.int64)
+    if fr != 0:
+        a = a.transpose(1, 0, 2)
+        for _ in range(passes):
+            a = _box_blur(a, fr)
+        a = a.transpose(1, 0, 2)
+        for _ in range(passes):
+            a = _box_blur(a, fr)
+    return a
 
 
 F32 = np.float32
@@ -77,10 +147,8 @@ def _hue(a, hue):
 
 
 def cpu_augment(img, p, OUT, mean=MEAN, std=STD):
-    crop = img[p.crop_top:p.crop_top + p.crop_h, p.crop_left:p.crop_left + p.crop_w].astype(np.float64)
-    tmp = np.stack([np.tensordot(w, crop[:, lo:hi], axes=(0, 1)) for lo, hi, w in _coeffs(p.crop_w, OUT)], 1)       # [h, OUT, 3]
-    a = np.stack([np.tensordot(w, tmp[lo:hi], axes=(0, 0)) for lo, hi, w in _coeffs(p.crop_h, OUT)], 0)              # [OUT, OUT, 3]
-    a = np.rint(np.clip(a, 0, 255))
+    crop = img[p.crop_top:p.crop_top + p.crop_h, p.crop_left:p.crop_left + p.crop_w]
+    a = resize_pil(crop, OUT).astype(np.float64)
     if p.jitter:
         for k in range(4):
             op = (p.jitter_order >> (2 * k)) & 3
@@ -95,20 +163,10 @@ def cpu_augment(img, p, OUT, mean=MEAN, std=STD):
     if p.grayscale:
         a = _luma(a)[..., None].repeat(3, -1)
     if p.blur_sigma > 0:
-        rad = min(int(np.ceil(3.0 * np.float32(p.blur_sigma))), 15)
-        g = np.exp(-0.5 * np.arange(-rad, rad + 1) ** 2 / np.float64(np.float32(p.blur_sigma)) ** 2)
-        for axis in (1, 0):
-            acc, nrm = np.zeros_like(a), np.zeros(a.shape[:2] + (1,))
-            for d, wgt in zip(range(-rad, rad + 1), g):
-                sl_dst = [slice(None)] * 3
-                sl_src = [slice(None)] * 3
-                sl_dst[axis] = slice(max(0, -d), OUT - max(0, d))
-                sl_src[axis] = slice(max(0, d), OUT - max(0, -d))
-                acc[tuple(sl_dst)] += wgt * a[tuple(sl_src)]
-                nrm[tuple(sl_dst[:2]) + (slice(None),)] += wgt
-            a = acc / nrm
-        a = np.rint(np.clip(a, 0, 255))
+        a = gaussian_blur_pil(a, p.blur_sigma).astype(np.float64)
     if p.flip:
         a = a[:, ::-1]
-    t = a.transpose(2, 0, 1) / 255.0
-    return ((t - np.array(mean).reshape(3, 1, 1)) / np.array(std).reshape(3, 1, 1)).astype(np.float32)
+    # ToTensor: uint8 -> float32 / 255; Normalize: (x - mean) / std, all float32 (torchvision's tensor ops)
+    t = (a.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    m, sd = np.array(mean, dtype=np.float32).reshape(3, 1, 1), np.array(std, dtype=np.float32).reshape(3, 1, 1)
+    return ((t - m).astype(np.float32) / sd).astype(np.float32)
