@@ -572,7 +572,7 @@ extern "C" int ilvlm_scatter_packed_rows(const float* dy, const int64_t* idx, co
 // ToTensor (/255) + Normalize(mean, std) of prototype/data/imagenet_dataloader.py:13-14,59-68 and the two augmentations of
 // MOCOV2_single whose effect is a pure function of the pixels once their coin is tossed: RandomHorizontalFlip (flag bit 0)
 // and RandomGrayscale (flag bit 1; PIL's ITU-R 601-2 luma (19595 R + 38470 G + 7471 B + 32768) >> 16, replicated).
-struct ImgNorm { float mean[3], inv_std[3]; };
+struct ImgNorm { float mean[3], std[3]; };
 __global__ __launch_bounds__(256) void image_u8_kernel(const unsigned char* __restrict__ src, const unsigned char* __restrict__ flags,
                                                        float* __restrict__ dst, int H, int W, int nhwc, ImgNorm nm) {
     const int b = blockIdx.z, y = blockIdx.y;
@@ -591,7 +591,8 @@ __global__ __launch_bounds__(256) void image_u8_kernel(const unsigned char* __re
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-        dst[((long)b * 3 + ch) * plane + (long)y * W + x] = ((float)px[ch] / 255.0f - nm.mean[ch]) * nm.inv_std[ch];
+        dst[((long)b * 3 + ch) * plane + (long)y * W + x] =
+            __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[ch], 255.0f), nm.mean[ch]), nm.std[ch]);     // float32 ToTensor / Normalize, division by division
 }
 
 extern "C" int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, const unsigned char* flags, float* dst, int B, int H,
@@ -602,7 +603,7 @@ extern "C" int ilvlm_image_u8_normalize(const unsigned char* src, int nhwc, cons
     for (int i = 0; i < 3; ++i) {
         ILVLM_REQUIRE(std3[i] > 0.f, "image_u8_normalize: std must be positive");
         nm.mean[i] = mean3[i];
-        nm.inv_std[i] = 1.0f / std3[i];
+        nm.std[i] = std3[i];
     }
     hipLaunchKernelGGL(image_u8_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, S_, src, flags, dst, H, W, nhwc ? 1 : 0, nm);
     ILVLM_LAUNCH_CHECK("image_u8_normalize");
