@@ -221,6 +221,8 @@ def main():
     sched = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=opt, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                             warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
     opt.prezero_grads = os.environ.get("ILVLM_PREZERO", "1") == "1"      # as the solver does (solver.build_optimizer)
+    if args.precision == "bf16" and not args.overlap_adamw:
+        opt.defer_late_blocks(int(os.environ.get("ILVLM_ADAMW_DEFER", "0")))   # as the solver does
     if args.overlap_adamw:
         # reference order (zero_grad, one backward, step): each block's AdamW goes out as soon as its gradients are final
         opt.overlap_backward(True)
@@ -429,6 +431,8 @@ def main():
         sc = scheduler_entry(dict(type="Cosine", kwargs=dict(optimizer=o, base_lr=5e-5, warmup_lr=5e-4, min_lr=0.0,
                                                              warmup_steps=500, max_iter=80000, last_iter=0, reset_steps=6000)))
         o.prezero_grads = os.environ.get("ILVLM_PREZERO", "1") == "1"
+        if precision == "bf16":
+            o.defer_late_blocks(int(os.environ.get("ILVLM_ADAMW_DEFER", "0")))
         dd.train()
         im, tk, pd, ln = synthetic_batch(batch, rank, dev)
         tx = (tk, pd, ops.PackedSeq(ln, tk.shape[1], dev))

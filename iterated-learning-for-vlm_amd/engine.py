@@ -56,6 +56,8 @@ class ParamArena:
         self.packed = None        # engine.PackedWeights of this arena (bf16 mode), for the optimizer
         self._prezero = None      # (event, G version) of a gradient memset issued ahead of zero_grad() (prezero_grads)
         self._zstream = None
+        self.late_event = None    # FusedAdamW.defer_late_blocks: the update of the blocks from late_from up, on the side stream
+        self.late_from = 0
         self._versions = None
         self.reducer = None       # comm.GradReducer installed by the data-parallel wrapper
         self.eager_opt = None     # FusedAdamW.overlap_backward(): the optimizer that updates blocks from inside backward
@@ -99,14 +101,38 @@ class ParamArena:
 
     def zero_grad(self):
         ev = self._prezero
+        self._zero_wait = None
         if ev is not None and self.G._version == ev[1]:
             # the optimizer zeroed the arena on a side stream right after its update (FusedAdamW.prezero_grads) and nothing
-            # has written gradients through torch since: only order this stream behind that memset
-            torch.cuda.current_stream(self.G.device).wait_event(ev[0])
+            # has written gradients through torch since: only order this stream behind that memset -- at once, or, while a
+            # deferred update (FusedAdamW.defer_late_blocks) still runs in front of that memset, when backward begins
+            # (finish_zero_grad; gradients are only written there): waiting here would hold the forward back behind the update
+            if self.late_event is not None:
+                self._zero_wait = ev[0]
+            else:
+                torch.cuda.current_stream(self.G.device).wait_event(ev[0])
             self._prezero = None
             return
         self._prezero = None
+        self.wait_late_update()                       # a deferred update may still be reading the gradients
         self.G.zero_()
+
+    def finish_zero_grad(self):
+        """called at the start of backward, on the stream backward starts from"""
+        ev = getattr(self, "_zero_wait", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.G.device).wait_event(ev)
+            self._zero_wait = None
+
+    def side_stream(self):
+        if self._zstream is None:
+            self._zstream = torch.cuda.Stream(device=self.G.device)
+        return self._zstream
+
+    def wait_late_update(self):
+        """order the current stream behind a deferred optimizer update (FusedAdamW.defer_late_blocks); cheap when it is done"""
+        if self.late_event is not None:
+            torch.cuda.current_stream(self.G.device).wait_event(self.late_event)
 
     def prezero_grads(self):
         """zero the gradient arena on a side stream, ordered after everything enqueued on the current stream (the optimizer's
@@ -377,6 +403,11 @@ class Engine:
         # that way calls mark_dirty() (or sets ILVLM_TRUST_SHADOW=0).
         vers = a.versions()
         current = self.trust_shadow and a.shadow_fresh and not swapped and vers == a._versions
+        # a deferred optimizer update (FusedAdamW.defer_late_blocks) is waited for by the towers in front of the first block it
+        # touched -- when this forward takes the tower calls with current copies; every other forward waits here
+        if a.late_event is not None and not (training and current and a.packed_fresh and self.tower_calls and self.precision == "bf16"):
+            a.wait_late_update()
+            a.late_event = None
         if not current:
             a.refresh_shadow()
         # the fragment-order images are current under the same conditions when the optimizer wrote them with its update
@@ -690,12 +721,22 @@ class Engine:
         xs [n, M, E] fp32 and the per-block workspaces n x stride bytes."""
         M, E = x0.shape
         descs = self._tower_descs(fmt, n, E, H, causal)
+        a = self.arena
         if descs is None:
+            a.wait_late_update()
             return None
         stride = max(ops.block_saved_bytes(d, M, B, L) for d in descs)
         xs = torch.empty((n, M, E), dtype=torch.float32, device=x0.device)
         ws = torch.empty(n * stride, dtype=torch.uint8, device=x0.device)
-        ops.tower_fwd(descs, x0, xs, ws, stride, B, L, seq)
+        k = a.late_from if a.late_event is not None else 0
+        if 0 < k < n:
+            # the optimizer is still updating the blocks from k up on its side stream: run the blocks below k, then wait
+            ops.tower_fwd(descs[:k], x0, xs[:k], ws[:k * stride], stride, B, L, seq)
+            a.wait_late_update()
+            ops.tower_fwd(descs[k:], xs[k - 1], xs[k:], ws[k * stride:], stride, B, L, seq)
+        else:
+            a.wait_late_update()
+            ops.tower_fwd(descs, x0, xs, ws, stride, B, L, seq)
         self.tower_count[0] += 1
         return xs[n - 1], TowerSaved(x0, xs, ws, stride)
 

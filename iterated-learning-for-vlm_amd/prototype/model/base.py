@@ -31,6 +31,7 @@ class _StepFn(torch.autograd.Function):
         saved, ctx.saved = ctx.saved, None
         if saved is None:
             raise RuntimeError("ilvlm: backward through the same forward twice is not supported")
+        ctx.model._eng.arena.finish_zero_grad()          # a gradient memset still queued behind a deferred optimizer update
         li = saved["head"][9]
         dli = torch.zeros_like(li) if dli is None else dli
         dlt = torch.zeros_like(li) if dlt is None else dlt

@@ -4,6 +4,7 @@ torch.optim.AdamW's layout ('step', 'exp_avg', 'exp_avg_sq') so reference checkp
 import bisect
 import ctypes as C
 import os
+import re
 
 import torch
 
@@ -33,6 +34,11 @@ class FusedAdamW(torch.optim.Optimizer):
         # gradients between step() and zero_grad()): step() zeroes the gradient arena itself, on a side stream beside the
         # next forward, and zero_grad() only waits for that -- the 0.11 ms memset leaves the critical path
         self.prezero_grads = False
+        # defer_late_blocks(K): step() updates what the next forward reads FIRST (embeddings, heads, the transformer blocks
+        # below K of each tower) on the calling stream and everything else -- the blocks from K up, most of the parameters -- on
+        # a side stream, beside the first blocks of that forward; the towers wait for it in front of their block K
+        self._defer_from = 0
+        self._late = None           # (chunk offsets, counts, groups, tile table) of the deferred part
 
     # -- arena binding -----------------------------------------------------------------------
     def _bind(self):
@@ -60,7 +66,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def _build_table(self):
         arena = self._arena
         sig = (tuple(tuple(bool(p.requires_grad) and (p._ilvlm_arena[1] not in arena.inactive) for p in g["params"])
-                     for g in self.param_groups), self._overlap, getattr(arena, "packed", None) is not None)
+                     for g in self.param_groups), self._overlap, getattr(arena, "packed", None) is not None, self._defer_from)
         if sig == self._sig:
             return
         offs, cnts, grps = [], [], []
@@ -71,6 +77,13 @@ class FusedAdamW(torch.optim.Optimizer):
         tiled = packed.names if (packed is not None and not self._overlap and arena.S is not None and
                                  os.environ.get("ILVLM_ADAMW_PACK", "1") == "1") else ()
         tiles = []
+        K = self._defer_from if not self._overlap else 0
+        blk = re.compile(r"^(?:visual|encode_text)\.transformer\.resblocks\.(\d+)\.")
+
+        def late(name):
+            m = blk.match(name)
+            return K > 0 and m is not None and int(m.group(1)) >= K
+        l_offs, l_cnts, l_grps, l_tiles = [], [], [], []
         for gi, g in enumerate(self.param_groups):
             for p, act in zip(g["params"], sig[0][gi]):
                 name = p._ilvlm_arena[1]
@@ -78,15 +91,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 if name in tiled:
                     r, c = p.shape
                     grp = gi if act else INACTIVE_GROUP
-                    tiles += [(o // 64, r, c, r0, c0, grp) for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+                    (l_tiles if late(name) else tiles).extend((o // 64, r, c, r0, c0, grp) for r0 in range(0, r, 64) for c0 in range(0, c, 64))
                     if act and p not in self.state:
                         m, v = self._views(p)
                         self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=m, exp_avg_sq=v)
                     continue
+                to = (l_offs, l_cnts, l_grps) if late(name) else (offs, cnts, grps)
                 for c in range(0, n, CHUNK):
-                    offs.append(o + c)
-                    cnts.append(min(CHUNK, n - c))
-                    grps.append(gi if act else INACTIVE_GROUP)
+                    to[0].append(o + c)
+                    to[1].append(min(CHUNK, n - c))
+                    to[2].append(gi if act else INACTIVE_GROUP)
                 if act and p not in self.state:
                     m, v = self._views(p)
                     self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=m, exp_avg_sq=v)
@@ -99,6 +113,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ccnt = torch.tensor(cnts, dtype=torch.int32, device=dev)
         self._cgrp = torch.tensor(grps, dtype=torch.int32, device=dev)
         self._tiles = torch.tensor(tiles, dtype=torch.int32, device=dev) if tiles else None
+        self._late = None
+        if l_offs or l_tiles:
+            self._late = (torch.tensor(l_offs, dtype=torch.int64, device=dev), torch.tensor(l_cnts, dtype=torch.int32, device=dev),
+                          torch.tensor(l_grps, dtype=torch.int32, device=dev),
+                          torch.tensor(l_tiles, dtype=torch.int32, device=dev) if l_tiles else None)
         self._sig = sig
         self._ranges = {}
 
@@ -115,14 +134,39 @@ class FusedAdamW(torch.optim.Optimizer):
         h.beta1, h.beta2, h.eps = float(b1), float(b2), float(eps)
         return h
 
-    def _launch(self, i0, i1, h, stream):
+    def _launch(self, i0, i1, h, stream, tab=None):
         if i1 <= i0:
             return
         arena = self._arena
+        coff, ccnt, cgrp = tab if tab is not None else (self._coff, self._ccnt, self._cgrp)
         L.check(L.load().ilvlm_adamw_step(arena.P.data_ptr(), arena.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                          arena.S.data_ptr() if arena.S is not None else None, self._coff.data_ptr() + 8 * i0,
-                                          self._ccnt.data_ptr() + 4 * i0, self._cgrp.data_ptr() + 4 * i0, int(i1 - i0),
+                                          arena.S.data_ptr() if arena.S is not None else None, coff.data_ptr() + 8 * i0,
+                                          ccnt.data_ptr() + 4 * i0, cgrp.data_ptr() + 4 * i0, int(i1 - i0),
                                           C.byref(h), stream), "adamw_step")
+
+    def _launch_tiles(self, tiles, h, stream):
+        arena, pk = self._arena, self._arena.packed
+        L.check(L.load().ilvlm_adamw_step_packed(arena.P.data_ptr(), arena.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                 arena.S.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr(), tiles.data_ptr(),
+                                                 int(tiles.shape[0]), C.byref(h), stream), "adamw_step_packed")
+
+    # -- update beside the next forward ---------------------------------------------------------
+    def defer_late_blocks(self, first_block=2):
+        """Opt-in for training loops in which nothing reads parameters between step() and the next forward except through
+        flush() (the solver and bench.py): step() updates on the calling stream only what the next forward reads first -- the
+        embeddings, the heads, the transformer blocks below `first_block` of each tower -- and the rest (blocks first_block.. of
+        both towers: two thirds of the parameters) on the gradient-memset side stream, where the 5 TB/s HBM stream of the update
+        runs beside the first blocks' GEMMs instead of in front of them.  The engine's tower calls wait for that part in front
+        of block `first_block` (engine.tower_fwd); any other reader goes through flush() / engine.prepare().  AdamW is
+        element-wise: bit-identical results.  0 switches it off.  bf16 mode (fp8 re-quantises every weight at the start of a
+        forward) and not with overlap_backward()."""
+        self._defer_from = max(0, int(first_block))
+
+    def flush(self):
+        """order the current stream behind a deferred part of the last step() (no-op without one)"""
+        a = self._arena
+        if a is not None and a.late_event is not None:
+            torch.cuda.current_stream(a.P.device).wait_event(a.late_event)
 
     # -- update inside backward ---------------------------------------------------------------
     def overlap_backward(self, enabled=True):
@@ -204,6 +248,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._ingest_loaded_state()
         arena = self._arena
         arena.wait_grads()
+        self.flush()                                   # the deferred part of the previous step owns the same moments
         if not self._eager:
             self._build_table()
         self._step += 1
@@ -217,11 +262,22 @@ class FusedAdamW(torch.optim.Optimizer):
         self._launch(cur, len(self._offs_host), h, st.cuda_stream)
         packed_done = False
         if self._tiles is not None:
-            pk = arena.packed
-            L.check(L.load().ilvlm_adamw_step_packed(arena.P.data_ptr(), arena.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                                     arena.S.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr(), self._tiles.data_ptr(),
-                                                     int(self._tiles.shape[0]), C.byref(h), st.cuda_stream), "adamw_step_packed")
+            self._launch_tiles(self._tiles, h, st.cuda_stream)
             packed_done = True
+        arena.late_event, arena.late_from = None, 0
+        if self._late is not None:
+            # the blocks from defer_from up: on the side stream, behind everything enqueued here (the gradients are final,
+            # the clip has scaled them); the gradient memset of prezero_grads follows on the same stream
+            zs = arena.side_stream()
+            zs.wait_stream(st)
+            coff, ccnt, cgrp, ltiles = self._late
+            self._launch(0, int(coff.shape[0]), h, zs.cuda_stream, (coff, ccnt, cgrp))
+            if ltiles is not None:
+                self._launch_tiles(ltiles, h, zs.cuda_stream)
+                packed_done = True
+            ev = torch.cuda.Event()
+            ev.record(zs)
+            arena.late_event, arena.late_from = ev, self._defer_from
         if self._eager:
             for o in self._ostreams:
                 if o is not st:
@@ -234,6 +290,7 @@ class FusedAdamW(torch.optim.Optimizer):
             arena.prezero_grads()
 
     def state_dict(self):
+        self.flush()
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
         return super().state_dict()

@@ -413,6 +413,86 @@ def test_adamw_keeps_the_fragment_order_weight_copies_current(monkeypatch):
     assert np.allclose(outs[0][6], outs[1][6], rtol=1e-2)
 
 
+def test_deferred_update_of_the_late_blocks_is_the_same_update():
+    """FusedAdamW.defer_late_blocks(K): the blocks from K up of both towers are updated on the side stream beside the next
+    forward, whose tower calls wait for them in front of block K.  (i) On the SAME gradients and state the deferred step
+    leaves parameters, moments, the bf16 shadow and both fragment-order images bit-identical to the plain step (frozen weight
+    in a deferred block included), and the gradient memset still lands; (ii) a training loop with it follows the plain loop
+    to the run-to-run noise, takes the split tower calls, and an evaluation forward / state_dict() in between see the
+    finished update."""
+    import bench as B
+    from ilvlm_amd.prototype.model import model_entry
+    from ilvlm_amd.prototype.loss_functions import ClipInfoCELoss
+    from ilvlm_amd.prototype.optimizer import optim_entry
+    from ilvlm_amd.prototype.utils.misc import param_group_all
+    images, tokens, pad, lens = B.synthetic_batch(16, 0, "cuda")
+    crit = ClipInfoCELoss()
+
+    def build(defer):
+        torch.manual_seed(0)
+        model = model_entry(dict(type="clip_fdt_vitb32", kwargs=B.fdt_kwargs("bf16"))).cuda().train()
+        model.visual.transformer.resblocks[7].mlp.c_fc.weight.requires_grad = False
+        opt = optim_entry(dict(type="AdamW", kwargs=dict(params=param_group_all(model, B.PCONFIG)[0], lr=1e-3, weight_decay=0.1,
+                                                         betas=[0.9, 0.98], eps=1e-8)))
+        opt.prezero_grads = True
+        opt.defer_late_blocks(defer)
+        return model, opt
+
+    # (i) same gradients, same state
+    model, opt = build(0)
+    (li, lt), _ = model(images, (tokens, pad, lens))
+    loss, _ = crit(li, lt)
+    opt.zero_grad(); loss.backward(); opt.step()                     # a first step: moments and tables exist
+    (li, lt), _ = model(images, (tokens, pad, lens))
+    loss, _ = crit(li, lt)
+    opt.zero_grad(); loss.backward()
+    torch.cuda.synchronize()
+    eng = model.engine
+    a = eng.arena
+    snap = [t.clone() for t in (a.P, a.G, a.S, opt.M, opt.V, eng.packed.fwd, eng.packed.bwd)]
+    results = []
+    for defer in (0, 3):
+        for t, s0 in zip((a.P, a.G, a.S, opt.M, opt.V, eng.packed.fwd, eng.packed.bwd), snap):
+            t.copy_(s0)
+        opt._step = 1
+        opt.defer_late_blocks(defer)
+        opt.step()
+        if defer:
+            assert a.late_event is not None and a.late_from == 3
+            late_tiles = opt._late[3]
+            assert late_tiles is not None and late_tiles.shape[0] > opt._tiles.shape[0]       # most of the weights are deferred
+        opt.flush()
+        torch.cuda.synchronize()
+        assert float(a.G.abs().max()) == 0.0
+        results.append([t.clone() for t in (a.P, a.S, opt.M, opt.V, eng.packed.fwd, eng.packed.bwd)])
+    for x, y in zip(*results):
+        assert torch.equal(x, y)
+    assert not torch.equal(results[0][0], snap[0])
+
+    # (ii) training loops
+    outs = []
+    for defer in (0, 2):
+        model, opt = build(defer)
+        losses = []
+        for step in range(4):
+            (li, lt), _ = model(images, (tokens, pad, lens))
+            loss, _ = crit(li, lt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            if step == 1:                                   # readers between two steps: an evaluation forward, a checkpoint
+                with torch.no_grad():
+                    model.eval(); model(images, (tokens, pad, lens)); model.train()
+                assert model.engine.arena.late_event is None
+                opt.state_dict()
+        torch.cuda.synchronize()
+        outs.append((model.engine.arena.P.clone(), losses, model.engine.tower_count[0]))
+    assert outs[0][2] == outs[1][2] > 0
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-3 * float(outs[0][0].abs().max())
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-2)
+
+
 def test_codebook_pin_of_the_smooth_phase_reaches_the_bf16_forward():
     """solver.keep_codebook_value() (reference train_solver.py:214,553) restores the codebook through `.data` right after an
     optimizer step that wrote the bf16 shadow of the UPDATED codebook: the next forward must read the pinned values (advisor
