@@ -19,6 +19,29 @@ def t_of(fn, rounds=6):
     return best * 1e3
 
 
+# round 4: the streaming kernel on fragment-order fp8 weights against the direct-to-LDS fp8 kernel, per shape, at the fp8
+# configuration's per-GPU batch 512 (rows 25600 / ~22600) and at 256; with the fc epilogue (bias + QuickGELU + pre-activation) on the
+# up-projection.  usage: fp8_gemm_bench.py pk
+if len(sys.argv) > 1 and sys.argv[1] == "pk":
+    for batch in (512, 256):
+        tot = [0.0, 0.0]
+        for tag, M, E in (("vit", 50 * batch, 768), ("txt", int(44.2 * batch), 512)):
+            for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E), ("qkv.dgrad", E, 3 * E),
+                               ("out.dgrad", E, E), ("fc.dgrad", E, 4 * E), ("proj.dgrad", 4 * E, E)):
+                a8 = torch.randint(0, 120, (M, k), device="cuda", dtype=torch.uint8); w8 = torch.randint(0, 120, (n, k), device="cuda", dtype=torch.uint8)
+                wp = ops.gemm_pack_b8(w8)
+                out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
+                kw = dict(bias=torch.randn(n, device="cuda"), aux=torch.empty(M, n, device="cuda", dtype=torch.bfloat16), act=1) if name == "fc" else {}
+                e5 = "dgrad" in name
+                td = t_of(lambda: ops.gemm_fp8(a8, w8, out, one, one, a_e5m2=e5, **kw))
+                tp = t_of(lambda: ops.gemm_fp8(a8, w8, out, one, one, a_e5m2=e5, b_packed=wp, **kw))
+                fl = 2.0 * M * n * k
+                tot[0] += td; tot[1] += tp
+                print("b%d %-14s M=%6d N=%5d K=%5d  direct-to-LDS %6.1f us %5.0f TF   streaming %6.1f us %5.0f TF   x%.2f" % (
+                    batch, tag + "." + name, M, n, k, td, fl / td / 1e6, tp, fl / tp / 1e6, td / tp), flush=True)
+        print("batch %d: sum direct-to-LDS %.0f us, streaming %.0f us, x%.2f" % (batch, tot[0], tot[1], tot[0] / tot[1]))
+    sys.exit(0)
+
 tot = [0.0, 0.0]
 for tag, M, E in (("vit", 12800, 768), ("pk", 11319, 512)):
     for name, n, k in (("qkv", 3 * E, E), ("out", E, E), ("fc", 4 * E, E), ("proj", E, 4 * E), ("qkv.dgrad", E, 3 * E), ("fc.dgrad", E, 4 * E),

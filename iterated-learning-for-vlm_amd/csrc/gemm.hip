@@ -2331,7 +2331,8 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         // streaming form: the caller offers the e4m3 B operand in fragment order (ilvlm_gemm_pack_b8 / the weight quantiser)
         static const int pk8_env = getenv("ILVLM_FP8_PK") ? atoi(getenv("ILVLM_FP8_PK")) : 1;
         const int variant8 = g_gemm_variant.load(std::memory_order_relaxed);
-        if (pk8_env && variant8 >= 15 && epi->b_packed && N % 16 == 0 && (long)N * K < (1L << 31) && ((long)(M - 1) * lda + K) < (1L << 31) &&
+        static const int pk8_min_k = getenv("ILVLM_FP8_PK_MIN_K") ? atoi(getenv("ILVLM_FP8_PK_MIN_K")) : 0;
+        if (pk8_env && variant8 >= 15 && K >= pk8_min_k && epi->b_packed && N % 16 == 0 && (long)N * K < (1L << 31) && ((long)(M - 1) * lda + K) < (1L << 31) &&
             aligned(epi->b_packed, 16)) {
             ep.tile_group = 0;
             const bool wide4 = N % 256 == 0;
