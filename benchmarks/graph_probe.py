@@ -11,6 +11,20 @@ import bench as BN
 from ilvlm_amd import ops
 
 
+_KEPT_EVENTS = []
+
+
+def keep_wait_stream_events():
+    """--keep-events: torch's Stream.wait_stream records a temporary Event on the other stream, waits for it and drops it at once
+    (hipEventDestroy while the capture is still open).  This variant keeps every such event alive until the process ends."""
+    def wait_stream(self, other):
+        ev = torch.cuda.Event()
+        ev.record(other)
+        self.wait_event(ev)
+        _KEPT_EVENTS.append(ev)
+    torch.cuda.Stream.wait_stream = wait_stream
+
+
 def capture(fn, warm=3):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -37,6 +51,8 @@ def model_and_batch(batch=64):
 
 
 def main(stage):
+    if "--keep-events" in sys.argv:
+        keep_wait_stream_events()
     torch.manual_seed(0)
     if stage == 1:
         a = torch.randn(1024, 768, device="cuda").to(torch.bfloat16)
@@ -94,15 +110,15 @@ def main(stage):
         fn = {3: fwd, 4: fwd_bwd, 5: step}[stage]
         if stage >= 4 and model.engine.wgrad_streams and "--force" not in sys.argv:
             # Recorded in profiles/round3/graph_probe.txt: with the companion weight-gradient streams, torch's capture_end
-            # (hipStreamEndCapture) segfaults on ROCm 7.2.  Round 4 reduced the capture to its stream pattern -- 96 forks of a
-            # second stream from the capturing one through a re-recorded ring of 64 events, one join, nested under a forked
-            # origin, issued from a second host thread (benchmarks/micro/graph_fork_probe.hip) -- and every variant captures,
-            # instantiates and replays correctly (profiles/round4/graph_fork_probe.txt): the fork / join pattern and the event
-            # ring of csrc/block.hip are legal and handled by the runtime; the crash needs torch's capture context (private
-            # allocator pool with frees of tensors last used on another captured stream).  Graphs are not shipped (a replay
-            # costs the host what the eager step costs it), so the probe refuses this configuration instead of crashing.
-            print("stage %d with companion weight-gradient streams is known to crash hipStreamEndCapture under torch's capture on "
-                  "ROCm 7.2 (profiles/round3/graph_probe.txt); run with ILVLM_WGRAD_STREAMS=0, or pass --force to try anyway" % stage)
+            # (hipStreamEndCapture) segfaults.  Round 4 found why: the HIP runtime the torch
+            # wheel bundles (roc-7.0.2) recurses without end in hip::Stream::EndCapture() when a stream forked from the capture's
+            # origin has itself forked a third stream -- the text tower's stream and its weight-gradient companion.  Pure-HIP
+            # reproducer: benchmarks/micro/graph_fork_probe.hip (passes on /opt/rocm's 7.2 runtime, crashes on the bundled one:
+            # profiles/round4/graph_fork_probe_both_runtimes.txt; native backtrace: graph_probe_capture_end_backtrace.txt).
+            # Graphs are not shipped (a replay costs the host what the eager step costs it), so the probe refuses this
+            # configuration instead of crashing.
+            print("stage %d with companion weight-gradient streams crashes hipStreamEndCapture of the HIP runtime torch bundles "
+                  "(roc-7.0.2: nested stream forks, profiles/round4/graph_fork_probe_both_runtimes.txt); run with ILVLM_WGRAD_STREAMS=0, or pass --force to try anyway" % stage)
             sys.exit(3)
         g, out = capture(fn)
         vals = []
