@@ -150,7 +150,9 @@ int ilvlm_gemm_set_tile_rows(int rows);
  * operand ring; the default), 256 = 256 x 128 (four waves of 128 x 64: a quarter fewer LDS-DMA pieces and transposing fragment
  * reads per MFMA; two stages, 96 KiB of LDS), 257 = the same tile single-stage (48 KiB); taken when M % 256 == 0.  -1 = default
  * (ILVLM_WGRAD_TILE).  Same K-slices, same order of K-tiles per output element: results equal the 128 x 128 tile's bit for bit at
- * one K-slice or with the slab workspace.  Tuning / test hook, process-wide atomic. */
+ * one K-slice or with the slab workspace.  The grouped fp8 weight gradients (ilvlm_wgrad_group, ILVLM_FP8_BF8A) follow the same
+ * selector: 128 = the 128 x 128 tile on the non-scaled fp8 MFMA, >= 256 = 256 x 128 tiles on the block-scaled MFMA for the output
+ * columns from 128 up (their default: ILVLM_FP8_WGRAD_TILE=256).  Tuning / test hook, process-wide atomic. */
 int ilvlm_gemm_set_wgrad_tile(int rows);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index

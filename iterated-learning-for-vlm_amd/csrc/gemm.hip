@@ -526,6 +526,24 @@ __device__ __forceinline__ long tr8_frag(const unsigned char* tile, int r16, int
     u.v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(tile + 128 * kr + 16 * chunk + 8 * (i & 1)));
     return u.l;
 }
+// The same fragment for the wide fp8 tile, addressed so that ONE per-lane register serves every row tile and k-step: the swizzle
+// ((kr >> 1) & 7 = (4 g + (i >> 2)) & 7) does not depend on the k-step (32 k-rows = 0 mod 8), the chunk bits (4..6) are disjoint
+// from the lane's other address bits when the tile is 128-byte aligned, hence
+//     address(row tile rt, k-step ks) = (addr0 ^ (rt << 4)) + 4096 ks,    addr0 = tile + 128 (8 g + (i >> 1)) + 8 (i & 1) + 16 swz
+// -- one XOR per row tile and an instruction offset, where tr8_frag's address arithmetic is loop-invariant per (rt, ks) and hipcc
+// hoists all 48 of them out of the K loop (they were what spilled the 256-register kernel).
+__device__ __forceinline__ unsigned tr8_addr0(const unsigned char* tile, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int swz = (4 * g + (i >> 2)) & 7;
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)tile + 128 * (8 * g + (i >> 1)) + 8 * (i & 1) + 16 * swz;
+}
+__device__ __forceinline__ long tr8_frag_w(unsigned addr0, int rt, int ks) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i lds_v2i;
+    union { v2i v; long l; } u;
+    u.v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(unsigned long long)((addr0 ^ (unsigned)(rt << 4)) + 4096u * ks));
+    return u.l;
+}
 #endif
 
 // Tile epilogue for SWAP fragments (lane owns row (l&15) and 4 consecutive columns 4*(l>>4).. of each 16x16 tile).
@@ -850,12 +868,19 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
     constexpr int NT = 64 * WM * WN;
     constexpr int TI = DBM / WM / 16, TJ = DBN / WN / 16;      // 16x16 tiles per wave
     constexpr int A_BYTES = DBM * BKT * 2, STAGE = (DBM + DBN) * BKT * 2;
-    constexpr bool TR8 = FP8 == 3;          // K-strided fp8 operands (fp8 weight gradients): K-tile = 128 k-rows
-    static_assert(!TR8 || (TA && TB && !SWAP && DBM == 128 && DBN == 128 && BKT == 64), "fp8 weight-gradient form");
+    // FP8 = 3: K-strided fp8 operands (fp8 weight gradients), K-tile = 128 k-rows, 128 x 128 tile.  FP8 = 4 (round 4): the same
+    // operands on a 256 x 128 tile (128 x 64 per wave) and the block-scaled MFMA: the A operand is TWO 128-row sub-operands in
+    // the proven LDS layout (rows m0.. and m0 + 128.., 16 KiB each; the waves of row half wm read only theirs), so a K-tile is
+    // 48 KiB for twice the products of the 128 x 128 tile's 32 KiB -- at the fp8 MFMA rate the 128 x 128 tile is bound by its
+    // operand traffic (DMA into LDS + transposing reads out of it), not by the matrix pipe.
+    constexpr bool TR8 = FP8 == 3 || FP8 == 4;
+    constexpr bool TR8W = FP8 == 4;
+    static_assert(!TR8 || (TA && TB && !SWAP && DBN == 128 && BKT == 64 && DBM == (TR8W ? 256 : 128)), "fp8 weight-gradient form");
+    static_assert(!TR8W || (WM == 2 && WN == 2 && NSTAGE == 1), "wide fp8 weight-gradient tile: 2 x 2 waves, single stage");
     constexpr int KTILE = TR8 ? 128 : BKT;
-    typedef typename std::conditional<TR8, DmaOperandTr8<DBM, NT>, DmaOperand<TA, DBM, NT, BKT>>::type OpA;
+    typedef typename std::conditional<TR8, DmaOperandTr8<128, NT>, DmaOperand<TA, DBM, NT, BKT>>::type OpA;
     typedef typename std::conditional<TR8, DmaOperandTr8<DBN, NT>, DmaOperand<TB, DBN, NT, BKT>>::type OpB;
-    constexpr int LOADS = OpA::NLOAD + OpB::NLOAD;
+    constexpr int LOADS = OpA::NLOAD * (TR8W ? 2 : 1) + OpB::NLOAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -900,7 +925,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    const bool rowsum = !SWAP && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;
+    const bool rowsum = !SWAP && !TR8W && ep.e.a_rowsum != nullptr && tn == 0 && wn == 0;
     f32x4 accb[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) accb[i] = (f32x4){0, 0, 0, 0};
@@ -928,6 +953,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
             STAMP(q0);
 #if ILVLM_GEMM_ABLATE != 2
             opa.issue(t, smem_raw, wave);
+            if constexpr (TR8W) opa.issue(t, smem_raw + 16384, wave, 128);      // rows m0 + 128 ..: 128 bytes further along the k-rows
             opb.issue(t, smem_raw + A_BYTES, wave);
 #endif
             STAMP(q1);
@@ -966,32 +992,42 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
 #if ILVLM_GEMM_ABLATE == 1
         if (K < 0)
 #endif
-        if constexpr (TR8 && ILVLM_FP8_SCALED_WGRAD) {
+        if constexpr (TR8 && (ILVLM_FP8_SCALED_WGRAD || TR8W)) {
             // scaled MFMA over the whole 128-row K-tile (see the K-contiguous form below): lane (g, byte 8 s + j) holds
-            // k = 32 s + 8 g + j of its operand row, for both operands.  Measured SLOWER than the non-scaled form here
-            // (weight gradients 470 vs 437 us per block pair: four transposing reads per fragment before the first MFMA),
-            // so it is compiled out by default.
+            // k = 32 s + 8 g + j of its operand row, for both operands.  On the 128 x 128 tile this measured SLOWER than the
+            // non-scaled form (weight gradients 470 vs 437 us per block pair: four transposing reads per fragment in front of
+            // four MFMAs), so there it is compiled out by default; the wide tile (FP8 = 4) runs eight row tiles against the four
+            // B fragments a wave holds.
             typedef int v8i __attribute__((ext_vector_type(8)));
             union F8 { long l[4]; v8i v; };
+            const unsigned char* asw = TR8W ? as + wm * 16384 : as;        // this wave's 128-row A sub-operand
+            const int arow0 = TR8W ? 0 : wm * (TI * 16);
+            const unsigned a_addr0 = tr8_addr0(asw, lane), b_addr0 = tr8_addr0(bs, lane);
             F8 fb8[TJ];
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fb8[j].l[ks] = tr8_frag(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
+                for (int ks = 0; ks < 4; ++ks) fb8[j].l[ks] = tr8_frag_w(b_addr0, wn * TJ + j, ks);
             F8 ones8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ones8.l[ks] = 0x3838383838383838L;       // e4m3 1.0
+            // (the wide tile carries no row sums: 32 more accumulator registers do not fit beside its 128, and a wave-uniform
+            // `if (rowsum)` around a fifth MFMA turned the accumulators into phi webs that spilled ~100 registers; the host gives
+            // the first 128 output columns -- the tiles that carry the bias gradient -- to the 128 x 128 kernel instead)
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 F8 fa8;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fa8.l[ks] = tr8_frag(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+                for (int ks = 0; ks < 4; ++ks) fa8.l[ks] = tr8_frag_w(a_addr0, (arow0 >> 4) + i, ks);
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)      // first operand e4m3 (x), second e5m2 (dy)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j].v, fa8.v, acc[i][j], 0, 1, 0, 0x7f7f7f7f, 0,
                                                                                  0x7f7f7f7f);
-                if (rowsum)
-                    accb[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8.v, fa8.v, accb[i], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if constexpr (!TR8W) {
+                    if (rowsum)
+                        accb[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8.v, fa8.v, accb[i], 0, 1, 0, 0x7f7f7f7f, 0,
+                                                                                   0x7f7f7f7f);
+                }
             }
         } else if constexpr (TR8) {
 #pragma unroll
@@ -1096,6 +1132,10 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
     if (ep.e.alpha_ptr) alpha *= *ep.e.alpha_ptr;
     if (ep.e.alpha_ptr2) alpha *= *ep.e.alpha_ptr2;
     const int mw = m0 + wm * (TI * 16), nw = n0 + wn * (TJ * 16);
+    // (256-register kernels: the epilogue's per-lane address arithmetic must not be hoisted above the K loop and held across it --
+    // it spilled 67 registers of the wide fp8 tile; an opaque copy of the lane index pins it here.  As gemm_bf16_pkp_kernel.)
+    int lane_e = lane;
+    if constexpr (DBM * DBN > 128 * 128) asm volatile("" : "+v"(lane_e));
 #if ILVLM_GEMM_ABLATE == 3
     if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -1156,20 +1196,20 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
                             acc[i][j] += x.f;
                         }
                 }
-                epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+                epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane_e, alpha, smem_raw + wave * 8192);
             }       // (the bias gradient of every slice still goes out below, as atomics on M floats)
         } else if (ep.plain_acc && split_k == 1) {
             // the only writer of this tile (grouped weight gradients at one K-slice): no atomics
-            epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+            epilogue_acc_tile<TI, TJ, 0, true>(ep, acc, mw, nw, lane_e, alpha, smem_raw + wave * 8192);
         } else {
-            epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane, alpha, smem_raw + wave * 8192);
+            epilogue_acc_tile<TI, TJ>(ep, acc, mw, nw, lane_e, alpha, smem_raw + wave * 8192);
         }
-        if (rowsum && lane < 16) {
+        if (rowsum && lane_e < 16) {
             // fp8 operands: the row sums are sums of quantised values, de-quantised by the A operand's scale alone
             const float ra = (FP8 != 0 && ep.e.alpha_ptr) ? *ep.e.alpha_ptr : 1.f;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                const int m = mw + i * 16 + lane;
+                const int m = mw + i * 16 + lane_e;
                 if (m < ep.M) atomicAdd(ep.e.a_rowsum + m, accb[i][0] * ra);
             }
         }
@@ -1210,16 +1250,16 @@ struct GroupArgs {
     int count, total;
 };
 
-template <int NSTAGE, int FP8>
-__global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void wgrad_group_kernel(GroupArgs g) {
+template <int NSTAGE, int FP8, int TM = 128>
+__global__ __launch_bounds__(256, TM == 256 ? 2 : (NSTAGE == 1 ? 3 : 2)) void wgrad_group_kernel(GroupArgs g) {
     const int wg = xcd_remap(blockIdx.x, g.total);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < ILVLM_WGRAD_GROUP_MAX; ++i)
         if (i < g.count && wg >= g.p[i].wg_begin) pi = i;
     const GroupProblem& P = g.p[pi];
-    dma_gemm_body<true, true, false, 128, 128, 2, 2, NSTAGE, 64, FP8>(P.A, P.lda, P.B, P.ldb, P.K, P.tiles_m, P.tiles_n, P.split_k,
-                                                                     P.ep, wg - P.wg_begin);
+    dma_gemm_body<true, true, false, TM, 128, 2, 2, NSTAGE, 64, FP8>(P.A, P.lda, P.B, P.ldb, P.K, P.tiles_m, P.tiles_n, P.split_k,
+                                                                    P.ep, wg - P.wg_begin);
 }
 
 // =====================================================================================
@@ -2570,7 +2610,18 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
     ILVLM_REQUIRE(rows > 0 && rows < (1L << 31) && split_target > 0, "wgrad_group: bad rows / split_target");
     const bool f8 = compute_dtype == ILVLM_FP8_BF8A;
     const int ktile = f8 ? 128 : 64, K = (int)rows;
-    long tiles = 0;
+    // fp8: 256 x 128 tiles on the block-scaled MFMA when every output has whole 256-row tiles and more than one tile column
+    // (ILVLM_FP8_WGRAD_TILE=128: off).  The wide kernel has no registers left for the bias gradient's row sums, so the launch is
+    // split by output COLUMNS: columns [128, k) of every product on the wide tile, columns [0, 128) -- the tile column that
+    // carries the row sums -- on the 128 x 128 kernel; two launches per block, each with its own K-slices.
+    static const int f8_tile_env = getenv("ILVLM_FP8_WGRAD_TILE") ? atoi(getenv("ILVLM_FP8_WGRAD_TILE")) : 256;
+    const int f8_tile_sel = g_wgrad_tile.load(std::memory_order_relaxed);            // ilvlm_gemm_set_wgrad_tile: tests, A/B
+    // (measured, same box: fp8 step at per-GPU batch 512 -- 25600 / 22600 token rows -- 23.27 -> 22.74 ms; at batch 256 13.14 ->
+    // 13.27 ms: half the K-tiles per tile, so the K-slices that refill the chip weigh more.  Hence a row threshold; an explicit
+    // selector overrides it.)
+    static const long f8_wide_min_rows = getenv("ILVLM_FP8_WGRAD_WIDE_MIN_ROWS") ? atol(getenv("ILVLM_FP8_WGRAD_WIDE_MIN_ROWS")) : 16384;
+    bool wide = f8 && (f8_tile_sel < 0 ? (f8_tile_env == 256 && rows >= f8_wide_min_rows) : f8_tile_sel >= 256);
+    for (int i = 0; i < count && wide; ++i) wide = problems[i].n > 0 && problems[i].n % 256 == 0 && problems[i].k > 128 && problems[i].k % 128 == 0;
     for (int i = 0; i < count; ++i) {
         const ilvlm_wgrad_problem& q = problems[i];
         ILVLM_REQUIRE(q.dy && q.x && q.gw && q.n > 0 && q.k > 0, "wgrad_group: problem %d: null pointer / bad shape", i);
@@ -2581,55 +2632,7 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         // both operands are addressed through 32-bit byte offsets of a buffer descriptor: they must end below 2 GiB
         ILVLM_REQUIRE(((rows - 1) * (long)q.n + q.n) * (f8 ? 1 : 2) < (1L << 31) && ((rows - 1) * (long)q.k + q.k) * (f8 ? 1 : 2) < (1L << 31),
                       "wgrad_group: problem %d: an operand of %ld rows exceeds 2 GiB", i, rows);
-        tiles += (long)ceil_div(q.n, 128) * ceil_div(q.k, 128);
     }
-    // K-slices: the count that minimises  rounds of workgroups x (K-tiles per slice + epilogue), in K-tile units -- a single
-    // writer adds its tile with plain loads and stores (~8 K-tiles' worth), K-slices meet in fp32 atomics (~25: they run at
-    // 1.3 TB/s and every workgroup of a round reaches them together).  ViT-B/32 block: 432 tiles -> 1 slice; text block:
-    // 192 tiles -> 2; ViT-L/14 block: 768 tiles -> 2 (three full rounds instead of one and a half).  ops.wgrad_group_split.
-    const int nt = ceil_div(K, ktile);
-    long cap = K >= 256 ? K / 256 : 1;
-    if (cap > 16) cap = 16;
-    if (cap > nt) cap = nt;
-    long split = 1;
-    double best = 1e30;
-    for (long sp = 1; sp <= cap; ++sp) {
-        const double rounds = (double)((tiles * sp + split_target - 1) / split_target);
-        const double c = rounds * ((double)((nt + sp - 1) / sp) + (sp == 1 ? 8.0 : 25.0));
-        if (c < best) { best = c; split = sp; }
-    }
-    GroupArgs g = {};
-    g.count = count;
-    int total = 0;
-    for (int i = 0; i < count; ++i) {
-        const ilvlm_wgrad_problem& q = problems[i];
-        GroupProblem& P = g.p[i];
-        P.A = (const bf16*)q.dy;
-        P.B = (const bf16*)q.x;
-        P.lda = q.n;
-        P.ldb = q.k;
-        P.K = K;
-        P.tiles_m = ceil_div(q.n, 128);
-        P.tiles_n = ceil_div(q.k, 128);
-        P.split_k = (int)split;
-        P.wg_begin = total;
-        total += P.tiles_m * P.tiles_n * (int)split;
-        P.ep.e.alpha = 1.0f;
-        P.ep.e.out_dtype = ILVLM_F32;
-        P.ep.e.accumulate = 1;
-        P.ep.e.a_rowsum = q.gb;
-        P.ep.e.alpha_ptr = f8 ? q.inv_g : nullptr;
-        P.ep.e.alpha_ptr2 = f8 ? q.inv_x : nullptr;
-        P.ep.Cf = q.gw;
-        P.ep.Cb = (bf16*)q.gw;
-        P.ep.ldc = q.k;
-        P.ep.M = q.n;
-        P.ep.N = q.k;
-        P.ep.vec_ok = (q.k % 4 == 0) && aligned(q.gw, 16);
-        P.ep.vec8_ok = 0;
-        P.ep.plain_acc = split == 1;
-    }
-    g.total = total;
     hipStream_t s = (hipStream_t)stream;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -2640,14 +2643,81 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr_err == hipSuccess)
             attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "wgrad_group: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    const int lds8 = lds_env > 32768 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 32768;
-    const int lds16 = lds_env > 65536 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 65536;
-    if (f8) hipLaunchKernelGGL((wgrad_group_kernel<1, 3>), dim3(total), dim3(256), lds8, s, g);
-    else hipLaunchKernelGGL((wgrad_group_kernel<2, 0>), dim3(total), dim3(256), lds16, s, g);
-    ILVLM_LAUNCH_CHECK("wgrad_group");
-    return ILVLM_OK;
+    const int nt = ceil_div(K, ktile);
+    // one launch over the output columns [c0, c1) of every product (c1 < 0: to the product's last column) on tm x 128 tiles
+    auto launch = [&](int c0, int c1, int tm, bool with_rowsum) -> int {
+        long tiles = 0;
+        for (int i = 0; i < count; ++i) {
+            const int kc = (c1 < 0 ? problems[i].k : c1) - c0;
+            tiles += (long)ceil_div(problems[i].n, tm) * ceil_div(kc, 128);
+        }
+        // K-slices: the count that minimises  rounds of workgroups x (K-tiles per slice + epilogue), in K-tile units -- a single
+        // writer adds its tile with plain loads and stores (~8 K-tiles' worth), K-slices meet in fp32 atomics (~25: they run at
+        // 1.3 TB/s and every workgroup of a round reaches them together).  ViT-B/32 block: 432 tiles -> 1 slice; text block:
+        // 192 tiles -> 2; ViT-L/14 block: 768 tiles -> 2 (three full rounds instead of one and a half).  ops.wgrad_group_split.
+        long cap = K >= 256 ? K / 256 : 1;
+        if (cap > 16) cap = 16;
+        if (cap > nt) cap = nt;
+        long split = 1;
+        double best = 1e30;
+        for (long sp = 1; sp <= cap; ++sp) {
+            const double rounds = (double)((tiles * sp + split_target - 1) / split_target);
+            const double c = rounds * ((double)((nt + sp - 1) / sp) + (sp == 1 ? 8.0 : 25.0));
+            if (c < best) { best = c; split = sp; }
+        }
+        GroupArgs g = {};
+        g.count = count;
+        int total = 0;
+        const int esz = f8 ? 1 : 2;
+        for (int i = 0; i < count; ++i) {
+            const ilvlm_wgrad_problem& q = problems[i];
+            const int kc = (c1 < 0 ? q.k : c1) - c0;
+            GroupProblem& P = g.p[i];
+            P.A = (const bf16*)q.dy;
+            P.B = (const bf16*)((const unsigned char*)q.x + (long)c0 * esz);
+            P.lda = q.n;
+            P.ldb = q.k;
+            P.K = K;
+            P.tiles_m = ceil_div(q.n, tm);
+            P.tiles_n = ceil_div(kc, 128);
+            P.split_k = (int)split;
+            P.wg_begin = total;
+            total += P.tiles_m * P.tiles_n * (int)split;
+            P.ep.e.alpha = 1.0f;
+            P.ep.e.out_dtype = ILVLM_F32;
+            P.ep.e.accumulate = 1;
+            P.ep.e.a_rowsum = with_rowsum ? q.gb : nullptr;
+            P.ep.e.alpha_ptr = f8 ? q.inv_g : nullptr;
+            P.ep.e.alpha_ptr2 = f8 ? q.inv_x : nullptr;
+            P.ep.Cf = q.gw + c0;
+            P.ep.Cb = (bf16*)(q.gw + c0);
+            P.ep.ldc = q.k;
+            P.ep.M = q.n;
+            P.ep.N = kc;
+            P.ep.vec_ok = (q.k % 4 == 0) && (c0 % 4 == 0) && aligned(q.gw, 16);
+            P.ep.vec8_ok = 0;
+            P.ep.plain_acc = split == 1;
+        }
+        g.total = total;
+        const int lds8 = lds_env > 32768 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 32768;
+        const int lds8w = lds_env > 49152 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 49152;
+        const int lds16 = lds_env > 65536 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 65536;
+        if (tm == 256) hipLaunchKernelGGL((wgrad_group_kernel<1, 4, 256>), dim3(total), dim3(256), lds8w, s, g);
+        else if (f8) hipLaunchKernelGGL((wgrad_group_kernel<1, 3>), dim3(total), dim3(256), lds8, s, g);
+        else hipLaunchKernelGGL((wgrad_group_kernel<2, 0>), dim3(total), dim3(256), lds16, s, g);
+        ILVLM_LAUNCH_CHECK("wgrad_group");
+        return ILVLM_OK;
+    };
+    if (wide) {
+        int rc = launch(128, -1, 256, false);
+        if (rc != ILVLM_OK) return rc;
+        return launch(0, 128, 128, true);
+    }
+    return launch(0, -1, 128, true);
 }
 
 #ifdef ILVLM_GEMM_STAMPS

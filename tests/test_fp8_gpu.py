@@ -175,6 +175,45 @@ def test_fp8_weight_gradient_gemm(T, M, N, split):
     assert float((out.cpu() - base - full).abs().max()) < 0.15 * float(full.abs().max())
 
 
+@pytest.mark.parametrize("rows,E", [(12800, 768), (11319, 512), (1000, 256), (640, 384)])
+def test_fp8_grouped_weight_gradients_on_both_tiles(rows, E):
+    """ilvlm_wgrad_group with fp8 operands (dY e5m2, X e4m3, both K-strided): the four products and bias gradients of a block,
+    accumulated into what the slots hold, against the de-quantised fp32 reference -- on the 128 x 128 tile (non-scaled fp8 MFMA)
+    and on the round-4 form: 256 x 128 tiles on the block-scaled MFMA for the output columns from 128 up, the first tile column
+    (which carries the bias gradient's row sums) on the 128 x 128 kernel.  Ragged reduction lengths; E = 384: 3 E = 1152 is not a
+    multiple of 256 rows, so that block falls back to the narrow tile as a whole."""
+    from ilvlm_amd import ops
+    dims = ((3 * E, E), (E, E), (4 * E, E), (E, 4 * E))
+    data = []
+    for i, (n, k) in enumerate(dims):
+        dy, x = rnd(rows, n, seed=10 + i) * 1e-4, rnd(rows, k, seed=20 + i)
+        sd, sx = 57344.0 / float(dy.abs().max()), 448.0 / float(x.abs().max())
+        dy8, x8 = to_f8(dy, sd, True), to_f8(x, sx, False)
+        ref = (dy8.float().t().double() @ x8.float().double()).float() / (sd * sx)
+        rs = dy8.float().double().sum(0).float() / sd
+        base = rnd(n, k, seed=30 + i) * float(ref.abs().max())
+        bb = rnd(n, seed=40 + i) * float(rs.abs().max())
+        data.append((dy8.view(torch.uint8).cuda(), x8.view(torch.uint8).cuda(), base, bb, ref, rs,
+                     torch.tensor([1.0 / sd], device="cuda"), torch.tensor([1.0 / sx], device="cuda")))
+    outs = {}
+    try:
+        for tile in (128, 256):
+            ops.gemm_set_wgrad_tile(tile)
+            prob = [(d[0], d[1], d[2].clone().cuda(), d[3].clone().cuda(), d[6], d[7]) for d in data]
+            ops.wgrad_group(prob, rows, fp8=True)
+            for (dy8, x8, gw, gb, _, _), d in zip(prob, data):
+                base, bb, ref, rs = d[2], d[3], d[4], d[5]
+                assert float((gw.cpu() - base - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-6 * float(base.abs().max()), tile
+                assert float((gb.cpu() - bb - rs).abs().max()) < 1e-4 * float(rs.abs().max()) + 1e-6 * float(bb.abs().max()), tile
+            outs[tile] = [p[2] for p in prob]
+    finally:
+        ops.gemm_set_wgrad_tile(-1)
+    if E % 256 != 0 and (3 * E) % 256 != 0:             # the whole block stayed on the narrow tile: same kernel, same K-slices
+        pass
+    for a, b in zip(outs[128], outs[256]):              # two MFMA forms of the same exact products: fp32 summation order only
+        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+
+
 def test_weight_quantisation_and_delayed_scaling():
     """the batched weight kernel: e4m3 copy and its transpose at the tensors' arena offsets, per-tensor amax; the scale
     update: history ring, scale = fmt_max / max(history), amax reset"""
