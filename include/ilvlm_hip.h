@@ -154,6 +154,12 @@ int ilvlm_gemm_set_tile_rows(int rows);
  * selector: 128 = the 128 x 128 tile on the non-scaled fp8 MFMA, >= 256 = 256 x 128 tiles on the block-scaled MFMA for the output
  * columns from 128 up (their default: ILVLM_FP8_WGRAD_TILE=256).  Tuning / test hook, process-wide atomic. */
 int ilvlm_gemm_set_wgrad_tile(int rows);
+/* Regime hint, process-wide: concurrent != 0 declares that the caller keeps several GEMM streams in flight (the engine's two
+ * towers with their weight-gradient companion streams).  ilvlm_gemm then picks, where two kernels compute the same result, the
+ * one measured best INSIDE such a step rather than alone -- today the bf16 weight gradients: single-stage 256 x 128 tiles
+ * (slower alone, 1.2-1.4 % faster steps) instead of two-stage 128 x 128 tiles.  Default 0.  Results do not depend on it beyond
+ * fp32 summation order between K-slices (bit-identical at one K-slice or through the slab workspace). */
+int ilvlm_gemm_set_concurrent(int concurrent);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +

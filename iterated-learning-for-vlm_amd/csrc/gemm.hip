@@ -878,9 +878,15 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
     static_assert(!TR8 || (TA && TB && !SWAP && DBN == 128 && BKT == 64 && DBM == (TR8W ? 256 : 128)), "fp8 weight-gradient form");
     static_assert(!TR8W || (WM == 2 && WN == 2 && NSTAGE == 1), "wide fp8 weight-gradient tile: 2 x 2 waves, single stage");
     constexpr int KTILE = TR8 ? 128 : BKT;
-    typedef typename std::conditional<TR8, DmaOperandTr8<128, NT>, DmaOperand<TA, DBM, NT, BKT>>::type OpA;
+    // 256-row K-strided A operands (the wide weight-gradient tiles, bf16 and fp8) are held as TWO 128-row sub-operands in the
+    // LDS layout of the 128 x 128 kernel -- the second is the first, 128 rows further along the k-rows -- and the waves of row
+    // half wm read only theirs: no new layout, no new bank-conflict analysis
+    constexpr bool SPLIT_A = TA && TB && !SWAP && DBM == 256;
+    constexpr int A_ROWS = SPLIT_A ? 128 : DBM;
+    typedef typename std::conditional<TR8, DmaOperandTr8<128, NT>, DmaOperand<TA, A_ROWS, NT, BKT>>::type OpA;
     typedef typename std::conditional<TR8, DmaOperandTr8<DBN, NT>, DmaOperand<TB, DBN, NT, BKT>>::type OpB;
-    constexpr int LOADS = OpA::NLOAD * (TR8W ? 2 : 1) + OpB::NLOAD;
+    constexpr int LOADS = OpA::NLOAD * (SPLIT_A ? 2 : 1) + OpB::NLOAD;
+    constexpr int A_EXTRA = TR8 ? 128 : 256;          // byte offset of operand row 128 inside a k-row (fp8 / bf16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -938,6 +944,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
     for (int d = 0; d < NSTAGE - 1; ++d)
         if (t_begin + d < t_end) {
             opa.issue(t_begin + d, smem_raw + d * STAGE, wave);
+            if constexpr (SPLIT_A) opa.issue(t_begin + d, smem_raw + d * STAGE + A_BYTES / 2, wave, A_EXTRA);
             opb.issue(t_begin + d, smem_raw + d * STAGE + A_BYTES, wave);
         }
     int st = 0;
@@ -953,7 +960,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
             STAMP(q0);
 #if ILVLM_GEMM_ABLATE != 2
             opa.issue(t, smem_raw, wave);
-            if constexpr (TR8W) opa.issue(t, smem_raw + 16384, wave, 128);      // rows m0 + 128 ..: 128 bytes further along the k-rows
+            if constexpr (SPLIT_A) opa.issue(t, smem_raw + A_BYTES / 2, wave, A_EXTRA);      // rows m0 + 128 ..
             opb.issue(t, smem_raw + A_BYTES, wave);
 #endif
             STAMP(q1);
@@ -979,6 +986,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
                 if (tn_ < t_end) {
                     const int sn = st == 0 ? NSTAGE - 1 : st - 1;     // (st + NSTAGE - 1) % NSTAGE
                     opa.issue(tn_, smem_raw + sn * STAGE, wave);
+                    if constexpr (SPLIT_A) opa.issue(tn_, smem_raw + sn * STAGE + A_BYTES / 2, wave, A_EXTRA);
                     opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
                 }
             }
@@ -1077,7 +1085,8 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
         for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = p8_frag<TA, DBM, BKT>(as, wm * (TI * 16) + i * 16, ks * 32, lane);
+            for (int i = 0; i < TI; ++i)
+                fa[i] = p8_frag<TA, A_ROWS, BKT>(SPLIT_A ? as + wm * (A_BYTES / 2) : as, (SPLIT_A ? 0 : wm * (TI * 16)) + i * 16, ks * 32, lane);
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[j] = p8_frag<TB, DBN, BKT>(bs, wn * (TJ * 16) + j * 16, ks * 32, lane);
 #pragma unroll
@@ -1112,6 +1121,7 @@ __device__ __forceinline__ void dma_gemm_body(const bf16* __restrict__ A, int ld
             if (tn_ < t_end) {
                 const int sn = st == 0 ? 2 : st - 1;
                 opa.issue(tn_, smem_raw + sn * STAGE, wave);
+                if constexpr (SPLIT_A) opa.issue(tn_, smem_raw + sn * STAGE + A_BYTES / 2, wave, A_EXTRA);
                 opb.issue(tn_, smem_raw + sn * STAGE + A_BYTES, wave);
             }
         }
@@ -2165,6 +2175,7 @@ int launch_pk8(const void* A8, int lda, const void* Bp8, int K, int M, int N, co
     return ILVLM_OK;
 }
 
+std::atomic<int> g_concurrent{0};     // ilvlm_gemm_set_concurrent: the caller keeps several GEMM streams in flight
 std::atomic<int> g_wgrad_tile{-1};    // -1 = ILVLM_WGRAD_TILE (default 128); 128, 256 (two-stage 256 x 128) or 257 (single-stage 256 x 128)
 std::atomic<int> g_pk_ti{-1};         // -1 = ILVLM_PK_TI (default 8); 8, 6, 4 force a tile height, 0 = the cost model (tests, A/B)
 
@@ -2463,13 +2474,18 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
         }
         if (fast) {
             // both operands through LDS: 128x128x64 tile, 4 waves, one stage, 4 (store) / 3 (accumulate) workgroups per CU
-            // weight gradients on 256 x 128 workgroup tiles, 128 x 64 per wave (round 4, opt-in: ILVLM_WGRAD_TILE=256 /
+            // weight gradients on 256 x 128 workgroup tiles, 128 x 64 per wave (round 4; ILVLM_WGRAD_TILE=128 / 256 / 257,
             // ilvlm_gemm_set_wgrad_tile): 48 KiB of operands per K-tile for twice the MFMAs of the 128 x 128 tile's 32 KiB -- a quarter
             // fewer LDS-DMA pieces and transposing fragment reads per MFMA; 96 KiB (two stages) or 48 KiB (one) of LDS
-            static const int wg_tile_env = getenv("ILVLM_WGRAD_TILE") ? atoi(getenv("ILVLM_WGRAD_TILE")) : 128;
+            // Default: 128 x 128 two-stage for a caller that runs one GEMM at a time (best alone: 517 against 757 us per block
+            // pair), the single-stage 256 x 128 tile when the caller has declared several GEMM streams in flight
+            // (ilvlm_gemm_set_concurrent: the engine's towers + weight-gradient companions) -- there the wide tile's fewer
+            // vector-memory and LDS instructions per MFMA leave more of the CU to the other streams: step 16.79 -> 16.56 ms
+            // (ViT-B/32, three same-box pairs), 95.75 -> 94.63 ms (ViT-L/14); serial towers 21.16 -> 23.60 ms, hence the hint.
+            static const int wg_tile_env = getenv("ILVLM_WGRAD_TILE") ? atoi(getenv("ILVLM_WGRAD_TILE")) : -1;
             static const int wg_tile_mul = getenv("ILVLM_WGRAD_TILE_SPLIT_MUL") ? atoi(getenv("ILVLM_WGRAD_TILE_SPLIT_MUL")) : 1;
             const int wg_sel = g_wgrad_tile.load(std::memory_order_relaxed);
-            const int wg_tile = wg_sel < 0 ? wg_tile_env : wg_sel;
+            const int wg_tile = wg_sel >= 0 ? wg_sel : (wg_tile_env >= 0 ? wg_tile_env : (g_concurrent.load(std::memory_order_relaxed) ? 257 : 128));
             if (!swap && trans_a && trans_b && variant >= 15 && (wg_tile == 256 || wg_tile == 257) && M % 256 == 0) {
                 split_k *= wg_tile_mul;
                 if (split_k > nt) split_k = nt;
@@ -2521,6 +2537,12 @@ extern "C" int ilvlm_gemm(int compute_dtype, int trans_a, int trans_b, int M, in
     if (!trans_a && trans_b) return launch_f32<false, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     if (trans_a && !trans_b) return launch_f32<true, false>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
     return launch_f32<true, true>(a, lda, b, ldb, K, tm, tn, split_k, ep, s);
+}
+
+// regime hint (see the weight-gradient dispatch in ilvlm_gemm)
+extern "C" int ilvlm_gemm_set_concurrent(int concurrent) {
+    g_concurrent.store(concurrent ? 1 : 0, std::memory_order_relaxed);
+    return ILVLM_OK;
 }
 
 // tuning / test hook: workgroup tile of the bf16 weight-gradient kernel (-1 = default / ILVLM_WGRAD_TILE, 128, 256 = 256 x 128

@@ -389,6 +389,8 @@ class Engine:
     def prepare(self, training=False):
         """Adopt / re-check the parameters before a forward.  `training`: a forward whose backward will run (gradients
         enabled); only such a forward advances the fp8 delayed-scaling state (Fp8State.begin_step)."""
+        if training:      # regime hint for the C library's kernel choices (weight-gradient tile): towers + companions in flight?
+            ops.gemm_set_concurrent(self.concurrent_towers and self.wgrad_streams)
         if self.arena is None:
             self.arena = ParamArena(self.m, self.precision)
             self.arena.inactive = set(self.m.unused_parameter_names())

@@ -366,6 +366,11 @@ def gemm_set_wgrad_tile(rows=-1):
     L.check(L.load().ilvlm_gemm_set_wgrad_tile(int(rows)), "gemm_set_wgrad_tile")
 
 
+def gemm_set_concurrent(concurrent):
+    """regime hint: several GEMM streams in flight (towers + weight-gradient companions) -> kernels measured best inside the step"""
+    L.check(L.load().ilvlm_gemm_set_concurrent(int(bool(concurrent))), "gemm_set_concurrent")
+
+
 def gemm_set_persistent(slots=0, epi_sep=-1, stagger=-1):
     """persistent streaming kernel: workgroups per launch (0 = two per CU), epilogue LDS placement (-1 = default) and the start
     delay of each CU's second workgroup in cycles per K-tile (-1 = default)"""

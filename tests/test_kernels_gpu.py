@@ -966,8 +966,18 @@ def test_weight_gradient_on_256_row_tiles_equals_the_128_row_tiles(M, N, K, spli
                 assert float((out - base - ref).abs().max()) < 1e-3 * scale
                 assert float((rs - rs_ref).abs().max()) < 1e-3 * float(rs_ref.abs().max())
                 res[(t, use_slab)] = out
+        # the regime hint (several GEMM streams in flight: what the engine declares for its concurrent towers) selects the
+        # single-stage wide tile by itself; without it the default stays the 128 x 128 tile
+        if tile == 257:
+            ops.gemm_set_wgrad_tile(-1)
+            for hint in (True, False):
+                ops.gemm_set_concurrent(hint)
+                out = base.clone()
+                ops.gemm(a, b, out, trans_a=True, trans_b=True, accumulate=True, split_k=split, slab=slab)
+                assert torch.equal(out, res[(257 if hint else 128, True)])
     finally:
         ops.gemm_set_wgrad_tile(-1)
+        ops.gemm_set_concurrent(False)
     assert int(slab[1].abs().sum()) == 0
     if split == 1:
         assert torch.equal(res[(128, False)], res[(tile, False)])
