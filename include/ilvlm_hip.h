@@ -160,6 +160,7 @@ int ilvlm_gemm_set_wgrad_tile(int rows);
  * (slower alone, 1.2-1.4 % faster steps) instead of two-stage 128 x 128 tiles.  Default 0.  Results do not depend on it beyond
  * fp32 summation order between K-slices (bit-identical at one K-slice or through the slab workspace). */
 int ilvlm_gemm_set_concurrent(int concurrent);
+int ilvlm_gemm_get_concurrent(void);
 /* B operand of ilvlm_gemm in MFMA-fragment order (the `b_packed` epilogue field).  With Bop[n][k] = B[n * ldb + k]
  * (trans_b = 0) or B[k * ldb + n] (trans_b = 1): the 16 x 32 block (n / 16, k / 32) is one contiguous KiB, block index
  * (n / 16) * (K / 32) + k / 32, and lane l of a wave owns its bytes [16 l, 16 l + 16): Bop[16 (n/16) + (l & 15)][32 (k/32) +

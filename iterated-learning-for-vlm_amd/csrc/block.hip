@@ -383,10 +383,16 @@ extern "C" int ilvlm_block_bwd(const ilvlm_block* b, const float* x_in, const vo
     // launch capped to one workgroup per CU -- two towers already keep every CU supplied, so tails and atomics were never
     // exposed, while one launch of 432 workgroups that live 260 us each holds the LDS of the whole chip against the
     // input-gradient chain.  The fp8 form (single-stage, 32 KiB of LDS, three workgroups per CU) WINS: 13.31 -> 12.99 ms.
-    // Hence: ILVLM_WGRAD_GROUP unset = fp8 weight gradients only; 1 = always; 0 = never.
+    // Round 4: on the SINGLE-STAGE 256 x 128 tile (which ilvlm_wgrad_group takes for bf16 when the caller has declared several
+    // GEMM streams in flight and every output has whole 256-row tiles) the grouped bf16 launch wins too -- one K-slice, a single
+    // writer per tile, no atomics: 16.71 -> 16.53 ms at 512 slots, 16.2-16.3 ms at <= 160 (ViT-B/32 + FDT), 95.8 -> 91.7 ms
+    // (ViT-L/14); profiles/round4/step_ab_wgrad_grouped_wide.txt.
+    // Hence: ILVLM_WGRAD_GROUP unset = fp8 weight gradients, and bf16 ones under the concurrency hint at widths that are
+    // multiples of 256; 1 = always; 0 = never.
     static const int group_env = getenv("ILVLM_WGRAD_GROUP") ? atoi(getenv("ILVLM_WGRAD_GROUP")) : -1;
     WgradBatch batch;
-    WgradBatch* wb = (lp && (group_env > 0 || (group_env < 0 && f8wg))) ? &batch : nullptr;
+    const bool group16 = !f8wg && E % 256 == 0 && ilvlm_gemm_get_concurrent() != 0;
+    WgradBatch* wb = (lp && (group_env > 0 || (group_env < 0 && (f8wg || group16)))) ? &batch : nullptr;
     // proj: du = (dy W_proj) * quickgelu'(u), with its e5m2 copy from the epilogue
     TRY(linear_bwd(b, T, dy, g, b->proj_w, b->g_proj_w, b->g_proj_b, du, rows, E, 4 * E, ILVLM_ACT_QUICKGELU_BWD, u, wgrad_target, s, wg,
                    g8, b->proj_w8t, inv + F8_DOUT, inv + F8_PROJ_W, f8on ? du8 : nullptr, f8on ? sc + F8_DU : nullptr,

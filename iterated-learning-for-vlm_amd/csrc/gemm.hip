@@ -2545,6 +2545,8 @@ extern "C" int ilvlm_gemm_set_concurrent(int concurrent) {
     return ILVLM_OK;
 }
 
+extern "C" int ilvlm_gemm_get_concurrent(void) { return g_concurrent.load(std::memory_order_relaxed); }
+
 // tuning / test hook: workgroup tile of the bf16 weight-gradient kernel (-1 = default / ILVLM_WGRAD_TILE, 128, 256 = 256 x 128
 // two-stage, 257 = 256 x 128 single-stage)
 extern "C" int ilvlm_gemm_set_wgrad_tile(int rows) {
@@ -2667,6 +2669,8 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
             attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr_err == hipSuccess)
             attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel<1, 0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) ILVLM_FAIL((int)attr_err, "wgrad_group: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     const int nt = ceil_div(K, ktile);
@@ -2728,7 +2732,8 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         const int lds8 = lds_env > 32768 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 32768;
         const int lds8w = lds_env > 49152 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 49152;
         const int lds16 = lds_env > 65536 ? (lds_env > 160 * 1024 ? 160 * 1024 : lds_env) : 65536;
-        if (tm == 256) hipLaunchKernelGGL((wgrad_group_kernel<1, 4, 256>), dim3(total), dim3(256), lds8w, s, g);
+        if (tm == 256 && !f8) hipLaunchKernelGGL((wgrad_group_kernel<1, 0, 256>), dim3(total), dim3(256), lds8w, s, g);
+        else if (tm == 256) hipLaunchKernelGGL((wgrad_group_kernel<1, 4, 256>), dim3(total), dim3(256), lds8w, s, g);
         else if (f8) hipLaunchKernelGGL((wgrad_group_kernel<1, 3>), dim3(total), dim3(256), lds8, s, g);
         else hipLaunchKernelGGL((wgrad_group_kernel<2, 0>), dim3(total), dim3(256), lds16, s, g);
         ILVLM_LAUNCH_CHECK("wgrad_group");
@@ -2738,6 +2743,16 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         int rc = launch(128, -1, 256, false);
         if (rc != ILVLM_OK) return rc;
         return launch(0, 128, 128, true);
+    }
+    // bf16 under the regime hint (several GEMM streams in flight): the single-stage 256 x 128 tile, as ilvlm_gemm's weight gradients
+    bool wide16 = !f8 && (f8_tile_sel >= 0 ? f8_tile_sel == 257 : g_concurrent.load(std::memory_order_relaxed) != 0);
+    for (int i = 0; i < count && wide16; ++i) wide16 = problems[i].n % 256 == 0;
+    if (wide16) {
+        // one K-slice wherever the cost model allows it: every tile then has a single writer (16-byte load-add-store instead of
+        // atomics).  Measured in the step, same box: slot targets 32 ... 160 tie (16.1-16.4 ms), 256 +0.1 ms, 512 +0.2 ms
+        static const int wide_slots = getenv("ILVLM_WGRAD_GROUP_SLOTS_WIDE") ? atoi(getenv("ILVLM_WGRAD_GROUP_SLOTS_WIDE")) : 128;
+        if (split_target > wide_slots) split_target = wide_slots;
+        return launch(0, -1, 256, true);
     }
     return launch(0, -1, 128, true);
 }

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ilvlm_gemm_set_tile_rows": [i32],
     "ilvlm_gemm_set_wgrad_tile": [i32],
     "ilvlm_gemm_set_concurrent": [i32],
+    "ilvlm_gemm_get_concurrent": [],
     "ilvlm_gemm_pack_b": [i32, i32, i32, vp, i32, vp, vp],
     "ilvlm_pack_weights": [vp, vp, vp, vp, i32, vp],
     "ilvlm_wgrad_group": [i32, C.POINTER(WgradProblem), i32, i64, i32, vp],

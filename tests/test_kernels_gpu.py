@@ -760,7 +760,7 @@ def test_streaming_gemm_store_type_split_k(M, N, K, tb):
         ops.gemm_set_variant(16)
         base = torch.full((M, N), float("nan"), device="cuda")
         ops.gemm(a, w, base, trans_b=bool(tb), bias=bias, residual=res, b_packed=wp, slab=slab)     # 16: never splits
-        assert int((slab[0][:4096] != 0xff).sum()) == 0
+        assert int((slab[0][:4 << 20] != 0xff).sum()) == 0
         ops.gemm_set_variant(17)                                                                     # 17: splits where offered
         assert float((base - want).abs().max()) < 2e-5 * float(want.abs().max())
         first = None
@@ -773,8 +773,9 @@ def test_streaming_gemm_store_type_split_k(M, N, K, tb):
             else:
                 assert torch.equal(out, first), "launch %d differs from launch 0" % it
         assert int(slab[1].abs().sum()) == 0
-        # the split really happened: slabs were written (no 0xff pattern left at the start of the workspace) ...
-        assert int((slab[0][:4096] != 0xff).sum()) > 0
+        # the split really happened: slabs were written somewhere in the first tiles' slots (WHICH K-slice of a tile publishes
+        # its slab depends on who arrives last, so the very first bytes may stay untouched) ...
+        assert int((slab[0][:4 << 20] != 0xff).sum()) > 0
         # ... and changes the summation order: equal to the unsplit kernel to fp32 rounding, not bit for bit
         assert float((first - base).abs().max()) < 1e-5 * float(want.abs().max())
     finally:
