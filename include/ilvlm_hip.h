@@ -186,7 +186,11 @@ int ilvlm_pack_weights(const void* arena_bf16, void* fwd, void* bwd, const int32
  * each) minimises ceil(tiles * slices / slots) * (ceil(K-tiles / slices) + e), e = 8 K-tiles' worth for the plain epilogue of
  * one slice and 25 for the atomic one.  At one K-slice every tile has a single writer and is added with plain loads and
  * stores; the caller guarantees that no OTHER launch accumulates into the same gw concurrently (launches on one stream are
- * fine).  n_p, k_p multiples of 8 (fp8: 16). */
+ * fine).  n_p, k_p multiples of 8 (fp8: 16).  Under ilvlm_gemm_set_concurrent(1) bf16 problems whose n_p are multiples of 256 run
+ * the single-stage 256 x 128 tile at ONE K-slice per tile (slot target capped at ILVLM_WGRAD_GROUP_SLOTS_WIDE = 128); a NEGATIVE
+ * split_target lifts that cap ("spread": the caller knows that nothing else runs beside this launch -- the last block of a
+ * tower's backward -- and wants the chip filled).  fp8 problems with >= 16384 rows run 256 x 128 tiles on the block-scaled MFMA
+ * for the output columns from 128 up and the 128 x 128 tile for the first tile column (two launches). */
 #define ILVLM_WGRAD_GROUP_MAX 4
 typedef struct ilvlm_wgrad_problem {
     const void* dy;

@@ -163,9 +163,16 @@ int order_after(hipStream_t s, hipStream_t wg) {
     return ILVLM_OK;
 }
 
+// set by ilvlm_tower_bwd around the LAST block it processes (block 0): nothing of the tower's chain is left to run beside that
+// block's weight gradients, so they are cut into K-slices to fill the chip instead of running one slice per tile (ilvlm_wgrad_group:
+// a negative slot target = spread)
+static thread_local int t_tail_block = 0;
+
 int flush_wgrad(WgradBatch* wb, hipStream_t s, hipStream_t wg) {
     if (!wb || wb->n == 0) return ILVLM_OK;
-    static const int slots = getenv("ILVLM_WGRAD_GROUP_SLOTS") ? atoi(getenv("ILVLM_WGRAD_GROUP_SLOTS")) : 512;
+    static const int slots_env = getenv("ILVLM_WGRAD_GROUP_SLOTS") ? atoi(getenv("ILVLM_WGRAD_GROUP_SLOTS")) : 512;
+    static const int tail_spread = getenv("ILVLM_WGRAD_TAIL_SPREAD") ? atoi(getenv("ILVLM_WGRAD_TAIL_SPREAD")) : 1;
+    const int slots = (t_tail_block && tail_spread) ? -slots_env : slots_env;
     hipStream_t ws = s;
     if (wg && wg != s) {
         TRY(order_after(s, wg));
@@ -498,9 +505,13 @@ extern "C" int ilvlm_tower_bwd(const ilvlm_block* blocks, int n_blocks, const il
         const float* dx_f32 = top ? dtop_f32 : d_f32 + (size_t)(i + 1) * rows * E;
         const void* dx_lp = top ? dtop_lp : per_block[i + 1].din_lp;
         const void* dx8 = top ? nullptr : per_block[i + 1].din8;
-        TRY(ilvlm_block_bwd(&blocks[i], x_in, (const char*)saved + (size_t)i * saved_stride, dx_f32, dx_lp, d_f32 + (size_t)i * rows * E,
-                            g.din_lp, (char*)scratch + (size_t)i * scratch_stride, g.ln_ws, g.ln_ws_blocks, rows, B, L, Lcap, seq_offs,
-                            wgrad_target, stream, wgrad_stream, dx8, g.din8, g.din8_scale, g.din8_amax));
+        t_tail_block = i == 0 && n_blocks > 1;
+        const int rc_blk = ilvlm_block_bwd(&blocks[i], x_in, (const char*)saved + (size_t)i * saved_stride, dx_f32, dx_lp,
+                                           d_f32 + (size_t)i * rows * E, g.din_lp, (char*)scratch + (size_t)i * scratch_stride, g.ln_ws,
+                                           g.ln_ws_blocks, rows, B, L, Lcap, seq_offs, wgrad_target, stream, wgrad_stream, dx8, g.din8,
+                                           g.din8_scale, g.din8_amax);
+        t_tail_block = 0;
+        if (rc_blk) return rc_blk;
         if (done) done(i, user);
     }
     return ILVLM_OK;

@@ -2631,7 +2631,11 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
                                  void* stream) {
     ILVLM_REQUIRE(problems && count >= 1 && count <= ILVLM_WGRAD_GROUP_MAX, "wgrad_group: 1..%d problems", ILVLM_WGRAD_GROUP_MAX);
     ILVLM_REQUIRE(compute_dtype == ILVLM_BF16 || compute_dtype == ILVLM_FP8_BF8A, "wgrad_group: bf16 or fp8 (e5m2 dy) operands");
-    ILVLM_REQUIRE(rows > 0 && rows < (1L << 31) && split_target > 0, "wgrad_group: bad rows / split_target");
+    ILVLM_REQUIRE(rows > 0 && rows < (1L << 31) && split_target != 0, "wgrad_group: bad rows / split_target");
+    // split_target < 0: "spread" -- the caller knows nothing else runs beside this launch (the last block of a tower's backward):
+    // K-slices for |split_target| slots even on the wide bf16 tile, which otherwise runs one slice per tile
+    const bool spread = split_target < 0;
+    if (spread) split_target = -split_target;
     const bool f8 = compute_dtype == ILVLM_FP8_BF8A;
     const int ktile = f8 ? 128 : 64, K = (int)rows;
     // fp8: 256 x 128 tiles on the block-scaled MFMA when every output has whole 256-row tiles and more than one tile column
@@ -2751,7 +2755,7 @@ extern "C" int ilvlm_wgrad_group(int compute_dtype, const ilvlm_wgrad_problem* p
         // one K-slice wherever the cost model allows it: every tile then has a single writer (16-byte load-add-store instead of
         // atomics).  Measured in the step, same box: slot targets 32 ... 160 tie (16.1-16.4 ms), 256 +0.1 ms, 512 +0.2 ms
         static const int wide_slots = getenv("ILVLM_WGRAD_GROUP_SLOTS_WIDE") ? atoi(getenv("ILVLM_WGRAD_GROUP_SLOTS_WIDE")) : 128;
-        if (split_target > wide_slots) split_target = wide_slots;
+        if (!spread && split_target > wide_slots) split_target = wide_slots;
         return launch(0, -1, 256, true);
     }
     return launch(0, -1, 128, true);
