@@ -377,7 +377,10 @@ def main():
                             kernel="gemm_bf16_pk_kernel + gemm_bf16_dma_kernel (all bf16 MFMA GEMM launches of a step: the streaming "
                                    "kernel on fragment-packed weights for forward / input gradients with K >= 512, the "
                                    "direct-to-LDS kernels for the rest and the weight gradients); achieved = their FLOPs / the "
-                                   "sum of their durations with the towers serialised (HIP events on the launch stream)",
+                                   "sum of their durations with the towers serialised (HIP events on the launch stream).  The weight "
+                                   "gradients run the kernel the library picks for the regime: two-stage 128x128 tiles in this serial leg, "
+                                   "single-stage 256x128 tiles (slower alone, faster steps) when the towers run concurrently, i.e. in the "
+                                   "timed step and in in_step below",
                             launches_per_step=s["launches"] // nprof,
                             gemm_ms_per_step=round(s["ms"] / nprof, 3),
                             algorithmic_gflop_per_step=round(s["flops"] / nprof / 1e9, 1),
